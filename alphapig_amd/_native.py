@@ -1,0 +1,148 @@
+"""ctypes bindings for the two in-tree native libraries.
+
+There is NO fallback: if a library is missing the import error says how to build it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(PKG, "libalphapig_host.so")
+HIP_LIB = os.path.join(PKG, "libalphapig_hip.so")
+
+_host = None
+_hip = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class ApzhConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("n_in_row", C.c_int32),
+                ("n_games", C.c_int32), ("n_playout", C.c_int32), ("prior_is_f32", C.c_int32),
+                ("n_threads", C.c_int32), ("reserved", C.c_int32), ("c_puct", C.c_double)]
+
+
+class ApzConfig(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("c_in", C.c_int32),
+                ("n_filter", C.c_int32), ("n_blocks", C.c_int32), ("net_kind", C.c_int32),
+                ("max_batch", C.c_int32), ("device", C.c_int32)]
+
+
+def _ptr(t):
+    return C.POINTER(t)
+
+
+def host():
+    """libalphapig_host.so (include/alphapig_host.h)."""
+    global _host
+    if _host is not None:
+        return _host
+    if not os.path.exists(HOST_LIB):
+        raise NativeLibraryMissing(
+            "%s not built; run `python -m alphapig_amd.build host` (no pure-Python fallback)" % HOST_LIB)
+    L = C.CDLL(HOST_LIB)
+    vp, i32p, i16p, i8p, u8p, i64p, f32p, f64p, u32p = (C.c_void_p, _ptr(C.c_int32), _ptr(C.c_int16),
+                                                        _ptr(C.c_int8), _ptr(C.c_uint8), _ptr(C.c_int64),
+                                                        _ptr(C.c_float), _ptr(C.c_double), _ptr(C.c_uint32))
+    sig = {
+        "apzh_last_error": (C.c_char_p, []),
+        "apzh_version": (C.c_int, []),
+        "apzh_create": (vp, [_ptr(ApzhConfig)]),
+        "apzh_destroy": (None, [vp]),
+        "apzh_game_reset": (C.c_int, [vp, C.c_int, C.c_int]),
+        "apzh_game_set_position": (C.c_int, [vp, C.c_int, i16p, i8p, C.c_int, C.c_int]),
+        "apzh_game_do_move": (C.c_int, [vp, C.c_int, C.c_int]),
+        "apzh_game_status": (C.c_int, [vp, C.c_int, i32p]),
+        "apzh_game_history": (C.c_int, [vp, C.c_int, i16p, i8p, C.c_int]),
+        "apzh_game_has_a_winner": (C.c_int, [vp, C.c_int, i32p]),
+        "apzh_code_stride": (C.c_int, [C.c_int, C.c_int]),
+        "apzh_game_codes": (C.c_int, [vp, C.c_int, u8p]),
+        "apzh_codes_to_planes": (C.c_int, [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+        "apzh_advance": (C.c_int, [vp, i32p, C.c_int, i32p, u8p]),
+        "apzh_feed": (C.c_int, [vp, i32p, C.c_int, f32p, f32p]),
+        "apzh_feed_sparse": (C.c_int, [vp, C.c_int, i32p, f64p, C.c_int, C.c_double, C.c_int]),
+        "apzh_pending_path": (C.c_int, [vp, C.c_int, i16p, C.c_int]),
+        "apzh_playouts_done": (C.c_int, [vp, C.c_int]),
+        "apzh_set_playouts_done": (C.c_int, [vp, C.c_int, C.c_int]),
+        "apzh_set_n_playout": (C.c_int, [vp, C.c_int]),
+        "apzh_node_children": (C.c_int, [vp, C.c_int, C.c_int, i32p, i64p, f64p, i8p, f64p, i32p, C.c_int,
+                                         i64p, f64p]),
+        "apzh_set_prior_mode": (C.c_int, [vp, C.c_int]),
+        "apzh_root_visits_dense": (C.c_int, [vp, i32p, C.c_int, i32p, i32p]),
+        "apzh_update_with_move": (C.c_int, [vp, C.c_int, C.c_int]),
+        "apzh_play_move": (C.c_int, [vp, C.c_int, C.c_int, i32p]),
+        "apzh_stats": (C.c_int, [vp, C.c_int, i64p]),
+        "apzh_pure_get_move": (C.c_int, [vp, C.c_int, u32p, i32p, i32p, i64p, f64p, C.c_int, i32p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _host = L
+    return L
+
+
+HOST_SYMBOLS = ["apzh_last_error", "apzh_version", "apzh_create", "apzh_destroy", "apzh_game_reset",
+                "apzh_game_set_position", "apzh_game_do_move", "apzh_game_status", "apzh_game_history",
+                "apzh_game_has_a_winner", "apzh_code_stride", "apzh_game_codes", "apzh_codes_to_planes",
+                "apzh_advance", "apzh_feed", "apzh_feed_sparse", "apzh_pending_path", "apzh_playouts_done",
+                "apzh_set_playouts_done", "apzh_set_n_playout", "apzh_node_children", "apzh_set_prior_mode",
+                "apzh_root_visits_dense", "apzh_update_with_move", "apzh_play_move", "apzh_stats",
+                "apzh_pure_get_move"]
+
+HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create", "apz_destroy",
+               "apz_param_count", "apz_param_name", "apz_param_size", "apz_load_weights", "apz_forward",
+               "apz_forward_host", "apz_forward_codes_host", "apz_encode_planes", "apz_augment8",
+               "apz_conv3x3_bench", "apz_layer_io", "apz_sync", "apz_stream", "apz_kernel_time_ms"]
+
+
+def hip():
+    """libalphapig_hip.so (include/alphapig_hip.h)."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    if not os.path.exists(HIP_LIB):
+        raise NativeLibraryMissing(
+            "%s not built; run `python -m alphapig_amd.build hip` (the evaluator has no CPU fallback)" % HIP_LIB)
+    L = C.CDLL(HIP_LIB)
+    vp, f32p, u8p, i32p = C.c_void_p, _ptr(C.c_float), _ptr(C.c_uint8), _ptr(C.c_int32)
+    sig = {
+        "apz_last_error": (C.c_char_p, []),
+        "apz_version": (C.c_int, []),
+        "apz_device_count": (C.c_int, []),
+        "apz_create": (vp, [_ptr(ApzConfig)]),
+        "apz_destroy": (None, [vp]),
+        "apz_param_count": (C.c_int, [vp]),
+        "apz_param_name": (C.c_char_p, [vp, C.c_int]),
+        "apz_param_size": (C.c_int64, [vp, C.c_int]),
+        "apz_load_weights": (C.c_int, [vp, _ptr(C.c_char_p), _ptr(f32p), _ptr(C.c_int64), C.c_int]),
+        "apz_forward": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
+        "apz_forward_host": (C.c_int, [vp, f32p, C.c_int, f32p, f32p]),
+        "apz_forward_codes_host": (C.c_int, [vp, u8p, C.c_int, f32p, f32p]),
+        "apz_encode_planes": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+        "apz_augment8": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+        "apz_conv3x3_bench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+        "apz_layer_io": (C.c_int, [vp, C.c_int, f32p, C.c_int64]),
+        "apz_sync": (C.c_int, [vp]),
+        "apz_stream": (vp, [vp]),
+        "apz_kernel_time_ms": (C.c_int, [vp, C.c_int, f32p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _hip = L
+    return L
+
+
+def as_ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def check_c(arr, dtype):
+    if not (isinstance(arr, np.ndarray) and arr.dtype == dtype and arr.flags["C_CONTIGUOUS"]):
+        raise TypeError("expected C-contiguous %s array" % np.dtype(dtype).name)
+    return arr

@@ -644,25 +644,33 @@ int apzh_set_n_playout(apzh_pool *p, int n_playout) {
     return APZH_OK;
 }
 
-int apzh_root_children(apzh_pool *p, int gi, int32_t *acts, int64_t *visits, double *q, int8_t *qk,
-                       double *prior, int cap, int64_t *root2, double *root_q) {
+int apzh_node_children(apzh_pool *p, int gi, int node, int32_t *acts, int64_t *visits, double *q, int8_t *qk,
+                       double *prior, int32_t *child_ids, int cap, int64_t *node3, double *node_q) {
     CHECK_GAME(p, gi);
     Game &g = p->games[gi];
     Arena &t = g.tree[g.cur];
-    if (root2) { root2[0] = t.n[0]; root2[1] = t.qk[0]; }
-    if (root_q) root_q[0] = t.q[0];
-    if (t.first_child[0] < 0) return 0;
-    int nc = t.n_child[0];
+    if (node < 0 || node >= t.size()) return fail(APZH_E_ARG, "node index out of range");
+    if (node3) { node3[0] = t.n[node]; node3[1] = t.qk[node]; node3[2] = t.parent[node]; }
+    if (node_q) { node_q[0] = t.q[node]; node_q[1] = t.prior[node]; }
+    if (t.first_child[node] < 0) return 0;
+    int nc = t.n_child[node];
     if (cap < nc) return fail(APZH_E_ARG, "children buffer too small");
-    int32_t b = t.first_child[0];
+    int32_t b = t.first_child[node];
     for (int k = 0; k < nc; k++) {
         if (acts) acts[k] = t.action[b + k];
         if (visits) visits[k] = t.n[b + k];
         if (q) q[k] = t.q[b + k];
         if (qk) qk[k] = (int8_t)t.qk[b + k];
         if (prior) prior[k] = t.prior[b + k];
+        if (child_ids) child_ids[k] = b + k;
     }
     return nc;
+}
+
+int apzh_set_prior_mode(apzh_pool *p, int prior_is_f32) {
+    CHECK_POOL(p);
+    p->cfg.prior_is_f32 = prior_is_f32 ? 1 : 0;
+    return APZH_OK;
 }
 
 int apzh_root_visits_dense(apzh_pool *p, const int32_t *games, int n, int32_t *visits, int32_t *n_children) {

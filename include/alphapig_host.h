@@ -109,10 +109,15 @@ int apzh_playouts_done(apzh_pool *p, int g);
 int apzh_set_playouts_done(apzh_pool *p, int g, int k);
 int apzh_set_n_playout(apzh_pool *p, int n_playout);
 
-/* root inspection: children in insertion order -> count; any output pointer may be NULL.
- * root2[0]=N_root, root_q[0]=Q_root, root2[1]=qkind_root */
-int apzh_root_children(apzh_pool *p, int g, int32_t *acts, int64_t *visits, double *q,
-                       int8_t *qk, double *prior, int cap, int64_t *root2, double *root_q);
+/* node inspection (node 0 = root): children in insertion order -> count; any output pointer
+ * may be NULL.  node3[0]=N node3[1]=qkind node3[2]=parent index (-1 root);
+ * node_q[0]=Q node_q[1]=prior.  child_ids are node indices valid until the next
+ * feed / update_with_move of that game. */
+int apzh_node_children(apzh_pool *p, int g, int node, int32_t *acts, int64_t *visits, double *q,
+                       int8_t *qk, double *prior, int32_t *child_ids, int cap, int64_t *node3,
+                       double *node_q);
+/* 1: priors are float32 and c_puct*P is a float32 product; 0: float64 */
+int apzh_set_prior_mode(apzh_pool *p, int prior_is_f32);
 /* batched: visits[i][H*W] dense (0 where no child), n_children[i]; for MOVE_READY games */
 int apzh_root_visits_dense(apzh_pool *p, const int32_t *games, int n, int32_t *visits,
                            int32_t *n_children);
