@@ -1,0 +1,748 @@
+// libalphapig_hip.so -- C ABI (include/alphapig_hip.h) over the gfx950 kernels.
+// Host-side glue only: parameter table, BatchNorm folding + weight packing, buffer ownership,
+// launch sequencing on one HIP stream, HIP-event timing hooks.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "alphapig_hip.h"
+#include "conv3x3_mfma.h"
+#include "heads.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(APZ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+    } while (0)
+
+constexpr double BN_EPS = 1e-3;   // MXNet BatchNorm default (policy_value_net_mxnet.py:54,78,81)
+
+struct Param {
+    std::string name;
+    int64_t size;
+};
+
+struct ConvLayer {
+    std::string name;       // conv parameter prefix
+    std::string bn;         // BN parameter prefix
+    std::string mean_sfx, var_sfx;
+    bool fix_gamma;
+    int cin, cin_pad, cout;
+    bool residual;          // add the block input before ReLU
+    float* wpk = nullptr;
+    float* bias = nullptr;
+};
+
+struct Pending {
+    int cls;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct apz_engine {
+    apz_config cfg;
+    int hw = 0, code_stride = 0, num_cu = 256, cmax = 0, clast = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Param> params;
+    std::vector<ConvLayer> convs;
+    bool loaded = false;
+    // heads
+    float *w6 = nullptr, *b6 = nullptr, *wfc_pk = nullptr, *bfc = nullptr, *wv = nullptr, *bv = nullptr;
+    // device buffers
+    float* act[3] = {nullptr, nullptr, nullptr};
+    float *planes = nullptr, *featp = nullptr, *featv = nullptr, *probs = nullptr, *values = nullptr;
+    unsigned char* codes = nullptr;
+    int *perm_s = nullptr, *perm_p = nullptr;
+    // host pinned staging (apz_forward_host)
+    float *h_planes = nullptr, *h_probs = nullptr, *h_values = nullptr;
+    unsigned char* h_codes = nullptr;
+    int last_n = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+    double k_ms[APZ_K_COUNT] = {0};
+    long k_cnt[APZ_K_COUNT] = {0};
+};
+
+namespace {
+
+void add_param(apz_engine* e, const std::string& n, int64_t sz) { e->params.push_back({n, sz}); }
+
+void build_tables(apz_engine* e) {
+    const apz_config& c = e->cfg;
+    const int hw = e->hw;
+    auto conv_act = [&](const std::string& name, int cin, int cout, int k) {
+        add_param(e, name + "_weight", (int64_t)cout * cin * k * k);
+        add_param(e, name + "_bias", cout);
+        add_param(e, name + "_gamma", cout);
+        add_param(e, name + "_beta", cout);
+        add_param(e, name + "_mean", cout);
+        add_param(e, name + "_var", cout);
+    };
+    int last = 0;
+    if (c.net_kind == APZ_NET_RESNET) {
+        const int F = c.n_filter;
+        conv_act("res_conv1", c.c_in, F, 3);
+        e->convs.push_back({"res_conv1", "res_conv1", "_mean", "_var", true, c.c_in, (c.c_in + 3) / 4 * 4, F, false});
+        for (int i = 1; i <= c.n_blocks; i++) {
+            for (const char* ab : {"A", "B"}) {
+                const std::string cn = std::string("conv") + ab + std::to_string(i);
+                const std::string bn = std::string("bn") + ab + std::to_string(i);
+                add_param(e, cn + "_weight", (int64_t)F * F * 9);
+                add_param(e, cn + "_bias", F);
+                add_param(e, bn + "_gamma", F);
+                add_param(e, bn + "_beta", F);
+                add_param(e, bn + "_moving_mean", F);
+                add_param(e, bn + "_moving_var", F);
+                e->convs.push_back({cn, bn, "_moving_mean", "_moving_var", false, F, F, F, ab[0] == 'B'});
+            }
+        }
+        last = F;
+    } else {
+        static const char* names[6] = {"conv1", "conv2", "conv3", "conv4", "conv5", "conv_final"};
+        static const int widths[6] = {64, 64, 128, 128, 256, 256};
+        int prev = c.c_in;
+        for (int i = 0; i < 6; i++) {
+            conv_act(names[i], prev, widths[i], 3);
+            e->convs.push_back({names[i], names[i], "_mean", "_var", true, prev, (prev + 3) / 4 * 4, widths[i], false});
+            prev = widths[i];
+        }
+        last = prev;
+    }
+    conv_act("conv3_1_1", last, 4, 1);
+    add_param(e, "fc_3_1_1_weight", (int64_t)hw * 4 * hw);
+    add_param(e, "fc_3_1_1_bias", hw);
+    conv_act("conv3_2_1", last, 2, 1);
+    add_param(e, "fc_3_2_1_weight", 2 * hw);
+    add_param(e, "fc_3_2_1_bias", 1);
+    e->clast = last;
+    e->cmax = 0;
+    for (auto& l : e->convs) e->cmax = std::max(e->cmax, l.cout);
+}
+
+// scale/shift of an inference BatchNorm folded behind a conv with bias
+void fold_bn(const std::map<std::string, const float*>& P, const std::string& conv, const std::string& bn,
+             const std::string& mean_sfx, const std::string& var_sfx, bool fix_gamma, int cout,
+             std::vector<double>& scale, std::vector<double>& shift) {
+    const float* bias = P.at(conv + "_bias");
+    const float* gamma = P.at(bn + "_gamma");
+    const float* beta = P.at(bn + "_beta");
+    const float* mean = P.at(bn + mean_sfx);
+    const float* var = P.at(bn + var_sfx);
+    scale.resize(cout);
+    shift.resize(cout);
+    for (int o = 0; o < cout; o++) {
+        const double g = fix_gamma ? 1.0 : (double)gamma[o];
+        const double s = g / std::sqrt((double)var[o] + BN_EPS);
+        scale[o] = s;
+        shift[o] = ((double)bias[o] - (double)mean[o]) * s + (double)beta[o];
+    }
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+    if (!*dst) HIP_TRY(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return APZ_OK;
+}
+
+hipEvent_t get_event(apz_engine* e) {
+    if (!e->free_events.empty()) {
+        hipEvent_t ev = e->free_events.back();
+        e->free_events.pop_back();
+        return ev;
+    }
+    hipEvent_t ev;
+    hipEventCreate(&ev);
+    return ev;
+}
+
+struct Timed {
+    apz_engine* e;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(apz_engine* e_, int cls_) : e(e_), cls(cls_) {
+        if (e->profiling) {
+            a = get_event(e);
+            b = get_event(e);
+            hipEventRecord(a, e->stream);
+        }
+    }
+    ~Timed() {
+        if (e->profiling) {
+            hipEventRecord(b, e->stream);
+            e->pending.push_back({cls, a, b});
+        }
+    }
+};
+
+void resolve_pending(apz_engine* e) {
+    for (auto& p : e->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            e->k_ms[p.cls] += ms;
+            e->k_cnt[p.cls] += 1;
+        }
+        e->free_events.push_back(p.a);
+        e->free_events.push_back(p.b);
+    }
+    e->pending.clear();
+}
+
+template <int H, int W, int CT>
+int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using G = apz::ConvGeo<H, W>;
+    const int lds = G::lds_bytes(L.cin_pad);
+    static int configured_lds = -1;
+    auto kern = apz::conv3x3_mfma_kernel<H, W, CT>;
+    if (lds > configured_lds) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured_lds = lds;
+    }
+    // persistent grid: as many workgroups as fit at once, each loops over boards
+    int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(lds, 1)));
+    int grid = std::min(n, e->num_cu * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, resid, out, n, L.cin,
+                       L.cin_pad, 1);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int launch_conv(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    const int H = e->cfg.height, W = e->cfg.width, ct = L.cout / 64;
+    if (H == 15 && W == 15) {
+        if (ct == 2) return launch_conv_t<15, 15, 2>(e, L, in, resid, out, n);
+        if (ct == 1) return launch_conv_t<15, 15, 1>(e, L, in, resid, out, n);
+        if (ct == 4) return launch_conv_t<15, 15, 4>(e, L, in, resid, out, n);
+    } else if (H == 8 && W == 8) {
+        if (ct == 2) return launch_conv_t<8, 8, 2>(e, L, in, resid, out, n);
+        if (ct == 1) return launch_conv_t<8, 8, 1>(e, L, in, resid, out, n);
+        if (ct == 4) return launch_conv_t<8, 8, 4>(e, L, in, resid, out, n);
+    }
+    return fail(APZ_E_UNSUPPORTED, "conv3x3: unsupported board size / channel count");
+}
+
+// runs conv layers [0, upto] on e->planes; returns the buffer holding layer `upto`'s output
+int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** result) {
+    float *x = e->act[0], *t = e->act[1], *y = e->act[2];
+    const float* cur = planes;
+    const int nl = (int)e->convs.size();
+    for (int li = 0; li <= upto && li < nl; li++) {
+        const ConvLayer& L = e->convs[li];
+        Timed tm(e, li == 0 ? APZ_K_STEM : APZ_K_TRUNK);
+        if (e->cfg.net_kind == APZ_NET_RESNET) {
+            if (li == 0) {
+                int rc = launch_conv(e, L, cur, nullptr, x, n);
+                if (rc) return rc;
+                cur = x;
+            } else if (!L.residual) {   // convA: x -> t
+                int rc = launch_conv(e, L, x, nullptr, t, n);
+                if (rc) return rc;
+                cur = t;
+            } else {                    // convB: t (+x) -> y ; then y becomes the block output
+                int rc = launch_conv(e, L, t, x, y, n);
+                if (rc) return rc;
+                std::swap(x, y);
+                cur = x;
+            }
+        } else {
+            float* dst = (cur == x) ? t : x;
+            int rc = launch_conv(e, L, cur, nullptr, dst, n);
+            if (rc) return rc;
+            cur = dst;
+        }
+    }
+    *result = const_cast<float*>(cur);
+    return APZ_OK;
+}
+
+int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* values, float* logits,
+                float* vlogits) {
+    if (!e->loaded) return fail(APZ_E_STATE, "weights not loaded");
+    if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
+    if (n == 0) return APZ_OK;
+    float* trunk = nullptr;
+    int rc = run_trunk(e, planes, n, (int)e->convs.size() - 1, &trunk);
+    if (rc) return rc;
+    const int hw = e->hw;
+    {
+        Timed tm(e, APZ_K_HEAD_CONV);
+        hipLaunchKernelGGL(apz::head_conv1x1_kernel, dim3(std::min(n, e->num_cu * 8)), dim3(256), 0, e->stream, trunk,
+                           e->w6, e->b6, e->featp, e->featv, n, e->clast, hw);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Timed tm(e, APZ_K_HEAD_FC);
+        const int ntile = (hw + 15) / 16;
+        const int lds = 16 * std::max(4 * hw + 1, ntile * 16) * (int)sizeof(float);
+        const int grid = (n + 15) / 16;
+        const int tpw = (ntile + 3) / 4;
+        if (tpw <= 1) {
+            hipLaunchKernelGGL(apz::head_fc_kernel<1>, dim3(grid), dim3(256), lds, e->stream, e->featp, e->featv,
+                               e->wfc_pk, e->bfc, e->wv, e->bv, probs, values, logits, vlogits, n, hw);
+        } else if (tpw <= 4) {
+            hipLaunchKernelGGL(apz::head_fc_kernel<4>, dim3(grid), dim3(256), lds, e->stream, e->featp, e->featv,
+                               e->wfc_pk, e->bfc, e->wv, e->bv, probs, values, logits, vlogits, n, hw);
+        } else {
+            return fail(APZ_E_UNSUPPORTED, "policy head: board too large");
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    e->last_n = n;
+    return APZ_OK;
+}
+
+// dihedral index tables (train_mxnet.py:115-135) on square boards
+void build_perms(int N, std::vector<int>& ps, std::vector<int>& pp) {
+    typedef std::vector<int> Grid;
+    auto rot90 = [N](const Grid& a) { Grid r(N * N); for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) r[i * N + j] = a[j * N + (N - 1 - i)]; return r; };
+    auto fliplr = [N](const Grid& a) { Grid r(N * N); for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) r[i * N + j] = a[i * N + (N - 1 - j)]; return r; };
+    auto flipud = [N](const Grid& a) { Grid r(N * N); for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) r[i * N + j] = a[(N - 1 - i) * N + j]; return r; };
+    Grid id(N * N);
+    for (int i = 0; i < N * N; i++) id[i] = i;
+    ps.clear();
+    pp.clear();
+    Grid s = id, p = flipud(id);
+    for (int k = 1; k <= 4; k++) {
+        s = rot90(s);
+        p = rot90(p);
+        Grid po = flipud(p);
+        ps.insert(ps.end(), s.begin(), s.end());
+        pp.insert(pp.end(), po.begin(), po.end());
+        Grid sf = fliplr(s), pf = flipud(fliplr(p));
+        ps.insert(ps.end(), sf.begin(), sf.end());
+        pp.insert(pp.end(), pf.begin(), pf.end());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* apz_last_error(void) { return g_err.c_str(); }
+int apz_version(void) { return 1; }
+
+int apz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void apz_destroy(apz_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    resolve_pending(e);
+    for (auto ev : e->free_events) hipEventDestroy(ev);
+    for (auto& l : e->convs) {
+        if (l.wpk) hipFree(l.wpk);
+        if (l.bias) hipFree(l.bias);
+    }
+    void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
+                   e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p};
+    for (void* p : dev)
+        if (p) hipFree(p);
+    void* host[] = {e->h_planes, e->h_probs, e->h_values, e->h_codes};
+    for (void* p : host)
+        if (p) hipHostFree(p);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+apz_engine* apz_create(const apz_config* cfg) {
+    if (!cfg || cfg->height < 1 || cfg->width < 1 || cfg->max_batch < 1 || (cfg->c_in != 9 && cfg->c_in != 4)) {
+        fail(APZ_E_ARG, "bad config (c_in must be 9 or 4)");
+        return nullptr;
+    }
+    if (!((cfg->height == 15 && cfg->width == 15) || (cfg->height == 8 && cfg->width == 8))) {
+        fail(APZ_E_UNSUPPORTED, "HIP kernels are instantiated for 15x15 and 8x8 boards");
+        return nullptr;
+    }
+    if (cfg->net_kind == APZ_NET_RESNET &&
+        ((cfg->n_filter != 64 && cfg->n_filter != 128 && cfg->n_filter != 256) || cfg->n_blocks < 0)) {
+        fail(APZ_E_UNSUPPORTED, "n_filter must be 64, 128 or 256");
+        return nullptr;
+    }
+    if (cfg->net_kind != APZ_NET_RESNET && cfg->net_kind != APZ_NET_SIMPLE) {
+        fail(APZ_E_ARG, "unknown net_kind");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        fail(APZ_E_HIP, "no HIP device: libalphapig_hip needs an AMD GPU (there is no CPU fallback)");
+        return nullptr;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) {
+        fail(APZ_E_ARG, "device ordinal out of range");
+        return nullptr;
+    }
+    apz_engine* e = new apz_engine();
+    e->cfg = *cfg;
+    e->hw = cfg->height * cfg->width;
+    e->code_stride = (e->hw + 1 + 15) / 16 * 16;
+    build_tables(e);
+    auto bail = [&](const char* what, hipError_t err) -> apz_engine* {
+        fail(APZ_E_HIP, std::string(what) + ": " + hipGetErrorString(err));
+        apz_destroy(e);
+        return nullptr;
+    };
+    hipError_t err;
+    if ((err = hipSetDevice(cfg->device)) != hipSuccess) return bail("hipSetDevice", err);
+    hipDeviceProp_t prop;
+    if ((err = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return bail("hipGetDeviceProperties", err);
+    e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", err);
+    const size_t B = cfg->max_batch, hw = e->hw;
+    const size_t act_bytes = B * e->cmax * hw * sizeof(float);
+    for (int i = 0; i < 3; i++)
+        if ((err = hipMalloc((void**)&e->act[i], act_bytes)) != hipSuccess) return bail("hipMalloc(act)", err);
+    if ((err = hipMalloc((void**)&e->planes, B * 9 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipMalloc((void**)&e->featp, B * 4 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipMalloc((void**)&e->featv, B * 2 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipMalloc((void**)&e->probs, B * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipMalloc((void**)&e->values, B * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipMalloc((void**)&e->codes, B * e->code_stride)) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipHostMalloc((void**)&e->h_planes, B * 9 * hw * sizeof(float))) != hipSuccess) return bail("hipHostMalloc", err);
+    if ((err = hipHostMalloc((void**)&e->h_probs, B * hw * sizeof(float))) != hipSuccess) return bail("hipHostMalloc", err);
+    if ((err = hipHostMalloc((void**)&e->h_values, B * sizeof(float))) != hipSuccess) return bail("hipHostMalloc", err);
+    if ((err = hipHostMalloc((void**)&e->h_codes, B * e->code_stride)) != hipSuccess) return bail("hipHostMalloc", err);
+    if (cfg->height == cfg->width) {
+        std::vector<int> ps, pp;
+        build_perms(cfg->height, ps, pp);
+        if (upload(&e->perm_s, ps) || upload(&e->perm_p, pp)) {
+            apz_destroy(e);
+            return nullptr;
+        }
+    }
+    return e;
+}
+
+int apz_param_count(apz_engine* e) { return e ? (int)e->params.size() : fail(APZ_E_ARG, "null engine"); }
+
+const char* apz_param_name(apz_engine* e, int i) {
+    if (!e || i < 0 || i >= (int)e->params.size()) return nullptr;
+    return e->params[i].name.c_str();
+}
+
+int64_t apz_param_size(apz_engine* e, int i) {
+    if (!e || i < 0 || i >= (int)e->params.size()) return -1;
+    return e->params[i].size;
+}
+
+int apz_load_weights(apz_engine* e, const char* const* names, const float* const* ptrs, const int64_t* sizes, int n) {
+    if (!e || !names || !ptrs || !sizes) return fail(APZ_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    std::map<std::string, const float*> P;
+    std::map<std::string, int64_t> S;
+    for (int i = 0; i < n; i++) {
+        P[names[i]] = ptrs[i];
+        S[names[i]] = sizes[i];
+    }
+    for (auto& p : e->params) {
+        auto it = S.find(p.name);
+        if (it == S.end()) return fail(APZ_E_ARG, "missing parameter " + p.name);
+        if (it->second != p.size)
+            return fail(APZ_E_ARG, "parameter " + p.name + " has " + std::to_string(it->second) + " elements, expected " +
+                                       std::to_string(p.size));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<double> scale, shift;
+    for (auto& L : e->convs) {
+        fold_bn(P, L.name, L.bn, L.mean_sfx, L.var_sfx, L.fix_gamma, L.cout, scale, shift);
+        const float* w = P.at(L.name + "_weight");   // [cout][cin][3][3]
+        const int n4 = L.cin_pad / 4, ncot = L.cout / 16;
+        std::vector<float> pk((size_t)ncot * n4 * 9 * 64, 0.f), bias(L.cout);
+        for (int cot = 0; cot < ncot; cot++)
+            for (int c4 = 0; c4 < n4; c4++)
+                for (int tap = 0; tap < 9; tap++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int co = cot * 16 + (lane & 15), ci = c4 * 4 + (lane >> 4);
+                        float v = 0.f;
+                        if (ci < L.cin) v = (float)((double)w[((size_t)co * L.cin + ci) * 9 + tap] * scale[co]);
+                        pk[(((size_t)cot * n4 + c4) * 9 + tap) * 64 + lane] = v;
+                    }
+        for (int o = 0; o < L.cout; o++) bias[o] = (float)shift[o];
+        int rc = upload(&L.wpk, pk);
+        if (rc) return rc;
+        rc = upload(&L.bias, bias);
+        if (rc) return rc;
+    }
+    // heads: two 1x1 conv_act (fix_gamma default) folded into one [6][C] matrix
+    {
+        const int C = e->clast, hw = e->hw;
+        std::vector<float> w6((size_t)6 * C), b6(6);
+        fold_bn(P, "conv3_1_1", "conv3_1_1", "_mean", "_var", true, 4, scale, shift);
+        const float* wp = P.at("conv3_1_1_weight");
+        for (int o = 0; o < 4; o++) {
+            for (int c = 0; c < C; c++) w6[(size_t)o * C + c] = (float)((double)wp[o * C + c] * scale[o]);
+            b6[o] = (float)shift[o];
+        }
+        fold_bn(P, "conv3_2_1", "conv3_2_1", "_mean", "_var", true, 2, scale, shift);
+        const float* wq = P.at("conv3_2_1_weight");
+        for (int o = 0; o < 2; o++) {
+            for (int c = 0; c < C; c++) w6[(size_t)(4 + o) * C + c] = (float)((double)wq[o * C + c] * scale[o]);
+            b6[4 + o] = (float)shift[o];
+        }
+        const float* wfc = P.at("fc_3_1_1_weight");   // [hw][4*hw]
+        const int K = 4 * hw, KS = hw, ntile = (hw + 15) / 16;
+        std::vector<float> pk((size_t)ntile * KS * 64, 0.f);
+        for (int nt = 0; nt < ntile; nt++)
+            for (int s = 0; s < KS; s++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int o = nt * 16 + (lane & 15), k = 4 * s + (lane >> 4);
+                    if (o < hw) pk[((size_t)nt * KS + s) * 64 + lane] = wfc[(size_t)o * K + k];
+                }
+        std::vector<float> bfc(P.at("fc_3_1_1_bias"), P.at("fc_3_1_1_bias") + hw);
+        std::vector<float> wv(P.at("fc_3_2_1_weight"), P.at("fc_3_2_1_weight") + 2 * hw);
+        std::vector<float> bv(P.at("fc_3_2_1_bias"), P.at("fc_3_2_1_bias") + 1);
+        int rc;
+        if ((rc = upload(&e->w6, w6)) || (rc = upload(&e->b6, b6)) || (rc = upload(&e->wfc_pk, pk)) ||
+            (rc = upload(&e->bfc, bfc)) || (rc = upload(&e->wv, wv)) || (rc = upload(&e->bv, bv)))
+            return rc;
+    }
+    e->loaded = true;
+    return APZ_OK;
+}
+
+int apz_forward(apz_engine* e, const void* planes_dev, int n, void* probs_dev, void* values_dev, void* logits_dev,
+                void* vlogits_dev) {
+    if (!e || !planes_dev || !probs_dev || !values_dev) return fail(APZ_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return forward_dev(e, (const float*)planes_dev, n, (float*)probs_dev, (float*)values_dev, (float*)logits_dev,
+                       (float*)vlogits_dev);
+}
+
+int apz_forward_host(apz_engine* e, const float* planes_host, int n, float* probs_host, float* values_host) {
+    if (!e || !planes_host || !probs_host || !values_host) return fail(APZ_E_ARG, "null argument");
+    if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
+    if (n == 0) return APZ_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t hw = e->hw, pin = (size_t)n * e->cfg.c_in * hw * sizeof(float);
+    std::memcpy(e->h_planes, planes_host, pin);
+    HIP_TRY(hipMemcpyAsync(e->planes, e->h_planes, pin, hipMemcpyHostToDevice, e->stream));
+    int rc = forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_probs, e->probs, n * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_values, e->values, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    resolve_pending(e);
+    std::memcpy(probs_host, e->h_probs, n * hw * sizeof(float));
+    std::memcpy(values_host, e->h_values, n * sizeof(float));
+    return APZ_OK;
+}
+
+int apz_forward_codes_async(apz_engine* e, const uint8_t* codes_pinned, int n, float* probs_pinned,
+                            float* values_pinned) {
+    if (!e || !codes_pinned || !probs_pinned || !values_pinned) return fail(APZ_E_ARG, "null argument");
+    if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
+    if (e->cfg.c_in != 9 && e->cfg.c_in != 4) return fail(APZ_E_STATE, "bad c_in");
+    if (n == 0) return APZ_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t hw = e->hw;
+    HIP_TRY(hipMemcpyAsync(e->codes, codes_pinned, (size_t)n * e->code_stride, hipMemcpyHostToDevice, e->stream));
+    int rc = apz_encode_planes(e, e->codes, n, e->cfg.c_in, e->planes);
+    if (rc) return rc;
+    rc = forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(probs_pinned, e->probs, n * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(values_pinned, e->values, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    return APZ_OK;
+}
+
+int apz_forward_codes_host(apz_engine* e, const uint8_t* codes_host, int n, float* probs_host, float* values_host) {
+    if (!e || !codes_host || !probs_host || !values_host) return fail(APZ_E_ARG, "null argument");
+    if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
+    if (n == 0) return APZ_OK;
+    std::memcpy(e->h_codes, codes_host, (size_t)n * e->code_stride);
+    int rc = apz_forward_codes_async(e, e->h_codes, n, e->h_probs, e->h_values);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    resolve_pending(e);
+    std::memcpy(probs_host, e->h_probs, (size_t)n * e->hw * sizeof(float));
+    std::memcpy(values_host, e->h_values, n * sizeof(float));
+    return APZ_OK;
+}
+
+void* apz_host_alloc(int64_t bytes) {
+    void* p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes) != hipSuccess) {
+        fail(APZ_E_HIP, "hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void apz_host_free(void* p) {
+    if (p) hipHostFree(p);
+}
+
+int apz_encode_planes(apz_engine* e, const void* codes_dev, int n, int n_planes, void* planes_dev) {
+    if (!e || !codes_dev || !planes_dev) return fail(APZ_E_ARG, "null argument");
+    if (n_planes != 9 && n_planes != 4) return fail(APZ_E_ARG, "n_planes must be 9 or 4");
+    if (n <= 0) return APZ_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    Timed tm(e, APZ_K_ENCODE);
+    const int total = n * e->hw;
+    hipLaunchKernelGGL(apz::encode_planes_kernel, dim3(std::min((total + 255) / 256, e->num_cu * 8)), dim3(256), 0,
+                       e->stream, (const unsigned char*)codes_dev, (float*)planes_dev, n, e->cfg.height, e->cfg.width,
+                       e->code_stride, n_planes);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_augment8(apz_engine* e, const void* planes_dev, const void* pi_dev, int n, int c, void* planes_out_dev,
+                 void* pi_out_dev) {
+    if (!e || !planes_dev || !pi_dev || !planes_out_dev || !pi_out_dev) return fail(APZ_E_ARG, "null argument");
+    if (!e->perm_s) return fail(APZ_E_UNSUPPORTED, "augmentation needs a square board");
+    if (n <= 0) return APZ_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const long total = (long)n * 8 * (c + 1) * e->hw;
+    hipLaunchKernelGGL(apz::augment8_kernel, dim3((int)std::min<long>((total + 255) / 256, e->num_cu * 16)), dim3(256),
+                       0, e->stream, (const float*)planes_dev, (const float*)pi_dev, e->perm_s, e->perm_p,
+                       (float*)planes_out_dev, (float*)pi_out_dev, n, c, e->hw);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_sync(apz_engine* e) {
+    if (!e) return fail(APZ_E_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    resolve_pending(e);
+    return APZ_OK;
+}
+
+void* apz_stream(apz_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+void* apz_device_alloc(apz_engine* e, int64_t bytes) {
+    void* p = nullptr;
+    if (!e || bytes <= 0 || hipSetDevice(e->cfg.device) != hipSuccess || hipMalloc(&p, (size_t)bytes) != hipSuccess) {
+        fail(APZ_E_HIP, "hipMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void apz_device_free(apz_engine* e, void* p) {
+    if (e && p) {
+        hipSetDevice(e->cfg.device);
+        hipFree(p);
+    }
+}
+
+int apz_memcpy_h2d(apz_engine* e, void* dst_dev, const void* src_host, int64_t bytes) {
+    if (!e || !dst_dev || !src_host || bytes < 0) return fail(APZ_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return APZ_OK;
+}
+
+int apz_memcpy_d2h(apz_engine* e, void* dst_host, const void* src_dev, int64_t bytes) {
+    if (!e || !dst_host || !src_dev || bytes < 0) return fail(APZ_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return APZ_OK;
+}
+
+int apz_conv3x3_bench(apz_engine* e, int layer, int n, int iters, int warmup, float* ms_out) {
+    if (!e || !ms_out) return fail(APZ_E_ARG, "null argument");
+    if (!e->loaded) return fail(APZ_E_STATE, "weights not loaded");
+    if (layer < 0 || layer >= (int)e->convs.size() || n < 1 || n > e->cfg.max_batch || iters < 1 || warmup < 0)
+        return fail(APZ_E_ARG, "bad layer / batch / iteration count");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const bool was = e->profiling;
+    e->profiling = false;
+    // produce this layer's real input from the planes resident in e->planes
+    const float* in = e->planes;
+    if (layer > 0) {
+        float* prev = nullptr;
+        int rc = run_trunk(e, e->planes, n, layer - 1, &prev);
+        if (rc) { e->profiling = was; return rc; }
+        in = prev;
+    }
+    const ConvLayer& L = e->convs[layer];
+    float* out = nullptr;
+    const float* resid = nullptr;
+    for (int i = 0; i < 3; i++)
+        if (e->act[i] != in && !out) out = e->act[i];
+    if (L.residual)
+        for (int i = 0; i < 3; i++)
+            if (e->act[i] != in && e->act[i] != out) resid = e->act[i];
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    int rc = APZ_OK;
+    for (int i = 0; i < warmup && !rc; i++) rc = launch_conv(e, L, in, resid, out, n);
+    HIP_TRY(hipEventRecord(a, e->stream));
+    for (int i = 0; i < iters && !rc; i++) rc = launch_conv(e, L, in, resid, out, n);
+    HIP_TRY(hipEventRecord(b, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    e->profiling = was;
+    if (rc) return rc;
+    ms_out[0] = ms / iters;
+    return APZ_OK;
+}
+
+int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
+    if (!e || !host_out) return fail(APZ_E_ARG, "null argument");
+    if (!e->loaded || e->last_n < 1) return fail(APZ_E_STATE, "run a forward first");
+    if (layer < 0 || layer >= (int)e->convs.size()) return fail(APZ_E_ARG, "bad layer");
+    const int64_t need = (int64_t)e->last_n * e->convs[layer].cout * e->hw;
+    if (count != need) return fail(APZ_E_ARG, "count must be n*C_out*H*W = " + std::to_string(need));
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    float* buf = nullptr;
+    const bool was = e->profiling;
+    e->profiling = false;
+    int rc = run_trunk(e, e->planes, e->last_n, layer, &buf);
+    e->profiling = was;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host_out, buf, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return APZ_OK;
+}
+
+int apz_set_profiling(apz_engine* e, int on) {
+    if (!e) return fail(APZ_E_ARG, "null engine");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    resolve_pending(e);
+    e->profiling = on != 0;
+    for (int i = 0; i < APZ_K_COUNT; i++) {
+        e->k_ms[i] = 0;
+        e->k_cnt[i] = 0;
+    }
+    return APZ_OK;
+}
+
+int apz_kernel_time_ms(apz_engine* e, int kernel_class, float* out2) {
+    if (!e || !out2 || kernel_class < 0 || kernel_class >= APZ_K_COUNT) return fail(APZ_E_ARG, "bad argument");
+    out2[0] = (float)e->k_ms[kernel_class];
+    out2[1] = (float)e->k_cnt[kernel_class];
+    return APZ_OK;
+}
+
+}  // extern "C"

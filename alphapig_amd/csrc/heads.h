@@ -1,0 +1,199 @@
+// Policy / value heads for gfx950.
+//
+//  head_conv1x1_kernel   both 1x1 convs (C -> 4 policy + 2 value channels) + folded BN + ReLU in
+//                        one pass over the trunk output (HBM-bound: reads C*H*W floats per board
+//                        once, coalesced), writing the flattened FC inputs [n][4*HW] and [n][2*HW].
+//  head_fc_kernel        policy FullyConnected as a dense fp32 MFMA GEMM (16 boards x HW outputs
+//                        x 4*HW deep per workgroup, v_mfma_f32_16x16x4_f32) + bias + row softmax
+//                        as a wavefront reduction; value FullyConnected (2*HW -> 1) as a wavefront
+//                        dot-reduce + tanh.
+// Reference graph: policy_value_net_mxnet.py:85-97 (conv3_1_1 / fc_3_1_1 / SoftmaxActivation,
+// conv3_2_1 / fc_3_2_1 / tanh); Dropout is the identity at inference.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv3x3_mfma.h"
+
+namespace apz {
+
+// w6 [6][C] (rows 0-3 policy, 4-5 value, BN folded), b6 [6]
+__global__ __launch_bounds__(256) void head_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w6,
+                                                           const float* __restrict__ b6, float* __restrict__ featp,
+                                                           float* __restrict__ featv, int n, int C, int HW) {
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const float* xb = x + (size_t)b * C * HW;
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
+            for (int c = 0; c < C; c++) {
+                const float v = xb[c * HW + p];
+                a0 = fmaf(w6[0 * C + c], v, a0);
+                a1 = fmaf(w6[1 * C + c], v, a1);
+                a2 = fmaf(w6[2 * C + c], v, a2);
+                a3 = fmaf(w6[3 * C + c], v, a3);
+                a4 = fmaf(w6[4 * C + c], v, a4);
+                a5 = fmaf(w6[5 * C + c], v, a5);
+            }
+            float* fp = featp + (size_t)b * 4 * HW;
+            float* fv = featv + (size_t)b * 2 * HW;
+            fp[0 * HW + p] = fmaxf(a0 + b6[0], 0.f);
+            fp[1 * HW + p] = fmaxf(a1 + b6[1], 0.f);
+            fp[2 * HW + p] = fmaxf(a2 + b6[2], 0.f);
+            fp[3 * HW + p] = fmaxf(a3 + b6[3], 0.f);
+            fv[0 * HW + p] = fmaxf(a4 + b6[4], 0.f);
+            fv[1 * HW + p] = fmaxf(a5 + b6[5], 0.f);
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One workgroup = 16 boards.  K = 4*HW (policy FC depth), NOUT = HW.
+//   A (features)  lane l: board = l&15, k = 4s + (l>>4)   from LDS, row stride K+1
+//   B (weights)   lane l: out = nt*16 + (l&15), k = 4s + (l>>4), pre-packed [NTILE][K/4][64]
+//   D  lane l, reg r: board = (l>>4)*4 + r, out = nt*16 + (l&15)
+// TPW = n-tiles per wave (ceil(NTILE / 4)); each wave keeps TPW independent accumulators so
+// the 40-cycle dependent-MFMA latency is covered.
+template <int TPW>
+__global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ featp, const float* __restrict__ featv,
+                                                      const float* __restrict__ wfc_pk, const float* __restrict__ bfc,
+                                                      const float* __restrict__ wv, const float* __restrict__ bv,
+                                                      float* __restrict__ probs, float* __restrict__ values,
+                                                      float* __restrict__ logits_out, float* __restrict__ vlogits_out,
+                                                      int n, int HW) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int K = 4 * HW, KS = HW;              // KS = K/4 k-steps
+    const int ntile = (HW + 15) / 16;
+    const int ldf = K + 1;                      // feature row stride
+    const int ldl = ntile * 16;                 // logits row stride
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    const int b0 = blockIdx.x * 16;
+    const int nb = min(16, n - b0);
+
+    // stage 16 feature rows (zero rows beyond n)
+    for (int i = tid; i < 16 * K; i += 256) {
+        const int r = i / K, c = i - r * K;
+        sm[r * ldf + c] = (r < nb) ? featp[(size_t)(b0 + r) * K + c] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* arow = sm + j * ldf + q;
+    for (int s = 0; s < KS; s++) {
+        const float a = arow[4 * s];
+#pragma unroll
+        for (int i = 0; i < TPW; i++) {
+            const int nt = wave + 4 * i;
+            if (nt < ntile) {   // wave-uniform
+                const float bw = wfc_pk[((size_t)nt * KS + s) * 64 + lane];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();            // features consumed; reuse LDS for the logits
+    float* lg = sm;
+#pragma unroll
+    for (int i = 0; i < TPW; i++) {
+        const int nt = wave + 4 * i;
+        if (nt < ntile) {
+            const int o = nt * 16 + j;
+            const float bb = (o < HW) ? bfc[o] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) lg[(q * 4 + r) * ldl + o] = acc[i][r] + bb;
+        }
+    }
+    __syncthreads();
+    // softmax: wave w owns boards 4w..4w+3 (SoftmaxActivation, instance mode)
+    for (int r = wave * 4; r < wave * 4 + 4; r++) {
+        if (r >= nb) break;
+        const float* row = lg + r * ldl;
+        float m = -INFINITY;
+        for (int o = lane; o < HW; o += 64) m = fmaxf(m, row[o]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int o = lane; o < HW; o += 64) s += expf(row[o] - m);
+        s = wave_sum(s);
+        const float inv = 1.0f / s;
+        for (int o = lane; o < HW; o += 64) {
+            const float l = row[o];
+            probs[(size_t)(b0 + r) * HW + o] = expf(l - m) * inv;
+            if (logits_out) logits_out[(size_t)(b0 + r) * HW + o] = l;
+        }
+        // value head: dot(featv[2*HW], wv) + bv -> tanh
+        const float* fv = featv + (size_t)(b0 + r) * 2 * HW;
+        float d = 0.f;
+        for (int o = lane; o < 2 * HW; o += 64) d = fmaf(fv[o], wv[o], d);
+        d = wave_sum(d) + bv[0];
+        if (lane == 0) {
+            values[b0 + r] = tanhf(d);
+            if (vlogits_out) vlogits_out[b0 + r] = d;
+        }
+    }
+}
+
+// ---- position codes -> input planes (Board.current_state, game.py:68-94 / :96-115) ---------
+// codes [n][stride] u8: byte m = h*W+w (un-flipped): 0 empty, 1+min(age,3) own, 5+min(age,3) opp;
+// byte HW = colour plane value.  planes [n][NP][H][W] with the vertical flip of game.py:94.
+__global__ void encode_planes_kernel(const unsigned char* __restrict__ codes, float* __restrict__ planes, int n, int H,
+                                     int W, int stride, int NP) {
+    const int HW = H * W;
+    const int total = n * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / HW, m = i - b * HW;
+        const int h = m / W, w = m - h * W;
+        const int o = (H - 1 - h) * W + w;
+        const unsigned char* cb = codes + (size_t)b * stride;
+        const int code = cb[m];
+        const float colour = cb[HW] ? 1.f : 0.f;
+        float* pb = planes + (size_t)b * NP * HW;
+        const int opp = code >= 5, age = (code - 1) & 3;
+        if (NP == 9) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float on = (code && k <= age) ? 1.f : 0.f;
+                pb[(6 - 2 * k) * HW + o] = opp ? 0.f : on;
+                pb[(7 - 2 * k) * HW + o] = opp ? on : 0.f;
+            }
+            pb[8 * HW + o] = colour;
+        } else {
+            pb[0 * HW + o] = (code && !opp) ? 1.f : 0.f;
+            pb[1 * HW + o] = (code && opp) ? 1.f : 0.f;
+            pb[2 * HW + o] = (code && age == 0) ? 1.f : 0.f;
+            pb[3 * HW + o] = colour;
+        }
+    }
+}
+
+// ---- 8-fold dihedral augmentation as a table-driven gather (train_mxnet.py:115-135) ---------
+// perm_s [8][HW], perm_p [8][HW]: out[k][..][i] = in[..][perm[k][i]]
+__global__ void augment8_kernel(const float* __restrict__ planes, const float* __restrict__ pi,
+                                const int* __restrict__ perm_s, const int* __restrict__ perm_p,
+                                float* __restrict__ planes_out, float* __restrict__ pi_out, int n, int C, int HW) {
+    const long total = (long)n * 8 * (C + 1) * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        long t = i / HW;
+        const int c = (int)(t % (C + 1));
+        t /= (C + 1);
+        const int k = (int)(t % 8);
+        const int b = (int)(t / 8);
+        if (c < C) {
+            planes_out[(((size_t)b * 8 + k) * C + c) * HW + p] = planes[((size_t)b * C + c) * HW + perm_s[k * HW + p]];
+        } else {
+            pi_out[((size_t)b * 8 + k) * HW + p] = pi[(size_t)b * HW + perm_p[k * HW + p]];
+        }
+    }
+}
+
+}  // namespace apz

@@ -1,0 +1,195 @@
+"""PolicyValueNet: drop-in for the reference evaluator (reference policy_value_net_mxnet.py:19-309
+and policy_value_net_mxnet_simple.py) on hand-written gfx950 HIP kernels.
+
+    PolicyValueNet(board_width, board_height, batch_size=512, n_blocks=8, n_filter=128,
+                   model_params=None)
+      .policy_value_fn(board) -> (zip(legal_moves, probs[legal] float32), value float32[1])
+      .policy_value(state_batch) -> (acts float32 [B, H*W], vals float32 [B, 1])
+
+No MXNet, no CPU fallback: construction fails loudly without libalphapig_hip.so or without an
+AMD GPU.  Extra (non-reference) entry points used by the batched engine: `evaluate_codes`
+(compact leaf codes, planes encoded on device) and `forward_planes`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native, weights
+from ._native import ApzConfig, as_ptr
+
+KERNEL_CLASSES = {"stem": 0, "trunk": 1, "head_conv": 2, "head_fc": 3, "encode": 4}
+
+
+class EvaluatorError(RuntimeError):
+    pass
+
+
+class PolicyValueNet(object):
+    def __init__(self, board_width, board_height, batch_size=512, n_blocks=8, n_filter=128,
+                 model_params=None, net_kind="resnet", c_in=9, device=0, seed=0, init_style="reference"):
+        self.L = _native.hip()
+        self.board_width, self.board_height = int(board_width), int(board_height)
+        self.batchsize = int(batch_size)
+        self.channelnum = int(c_in)
+        self._n_blocks, self._n_filter = int(n_blocks), int(n_filter)
+        self.net_kind = net_kind
+        self.hw = self.board_width * self.board_height
+        self.code_stride = (self.hw + 1 + 15) // 16 * 16
+        kind = {"resnet": 0, "simple": 1}[net_kind]
+        cfg = ApzConfig(self.board_height, self.board_width, self.channelnum, self._n_filter, self._n_blocks,
+                        kind, self.batchsize, int(device))
+        self._h = self.L.apz_create(C.byref(cfg))
+        if not self._h:
+            raise EvaluatorError("apz_create failed: %s" % self.L.apz_last_error().decode())
+        if model_params is None:
+            model_params = weights.init_params(net_kind, self.board_height, self.board_width, self.channelnum,
+                                               self._n_blocks, self._n_filter, seed=seed, style=init_style)
+        self.set_params(model_params)
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.apz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise EvaluatorError("%s (code %d)" % (self.L.apz_last_error().decode(), rc))
+        return rc
+
+    # ---- parameters
+    def param_table(self):
+        n = self._ck(self.L.apz_param_count(self._h))
+        return [(self.L.apz_param_name(self._h, i).decode(), int(self.L.apz_param_size(self._h, i)))
+                for i in range(n)]
+
+    def set_params(self, model_params):
+        """model_params: {name: array} or the reference's (arg_params, aux_params) pair."""
+        if isinstance(model_params, (tuple, list)) and len(model_params) == 2:
+            merged = dict(model_params[0])
+            merged.update(model_params[1])
+            model_params = merged
+        table = self.param_table()
+        keep = []
+        names = (C.c_char_p * len(table))()
+        ptrs = (C.POINTER(C.c_float) * len(table))()
+        sizes = (C.c_int64 * len(table))()
+        for i, (name, size) in enumerate(table):
+            if name not in model_params:
+                raise EvaluatorError("missing parameter %s" % name)
+            a = np.ascontiguousarray(np.asarray(model_params[name]), dtype=np.float32)
+            keep.append(a)
+            names[i] = name.encode()
+            ptrs[i] = as_ptr(a, C.c_float)
+            sizes[i] = a.size
+        self._ck(self.L.apz_load_weights(self._h, names, ptrs, sizes, len(table)))
+        self._params = {name: keep[i].copy() for i, (name, _) in enumerate(table)}
+
+    def get_policy_param(self):
+        return dict(self._params)
+
+    def save_model(self, model_file):
+        weights.save_params(self._params, model_file)
+
+    # ---- forward
+    def forward_planes(self, planes):
+        """planes [n, C, H, W] -> (probs float32 [n, HW], values float32 [n])."""
+        x = np.ascontiguousarray(planes, dtype=np.float32)
+        if x.ndim != 4 or x.shape[1:] != (self.channelnum, self.board_height, self.board_width):
+            raise ValueError("planes must be [n, %d, %d, %d]" % (self.channelnum, self.board_height, self.board_width))
+        n = x.shape[0]
+        probs = np.empty((n, self.hw), dtype=np.float32)
+        vals = np.empty(n, dtype=np.float32)
+        for s in range(0, n, self.batchsize):
+            k = min(self.batchsize, n - s)
+            self._ck(self.L.apz_forward_host(self._h, as_ptr(x[s:s + k], C.c_float), k,
+                                             as_ptr(probs[s:s + k], C.c_float), as_ptr(vals[s:s + k], C.c_float)))
+        return probs, vals
+
+    def forward_with_logits(self, planes):
+        """Test hook: -> (logits, probs, value_logits, values) for one batch <= batch_size."""
+        x = np.ascontiguousarray(planes, dtype=np.float32)
+        n = x.shape[0]
+        nbytes = lambda cnt: int(cnt) * 4
+        dev = [self.L.apz_device_alloc(self._h, nbytes(c)) for c in (x.size, n * self.hw, n, n * self.hw, n)]
+        if not all(dev):
+            raise EvaluatorError(self.L.apz_last_error().decode())
+        try:
+            self._ck(self.L.apz_memcpy_h2d(self._h, dev[0], x.ctypes.data, x.nbytes))
+            self._ck(self.L.apz_forward(self._h, dev[0], n, dev[1], dev[2], dev[3], dev[4]))
+            self._ck(self.L.apz_sync(self._h))
+            probs = np.empty((n, self.hw), np.float32)
+            vals = np.empty(n, np.float32)
+            logits = np.empty((n, self.hw), np.float32)
+            vlog = np.empty(n, np.float32)
+            for d, a in ((dev[1], probs), (dev[2], vals), (dev[3], logits), (dev[4], vlog)):
+                self._ck(self.L.apz_memcpy_d2h(self._h, a.ctypes.data, d, a.nbytes))
+        finally:
+            for d in dev:
+                self.L.apz_device_free(self._h, d)
+        return logits, probs, vlog, vals
+
+    def layer_output(self, layer, n):
+        """Test hook: output activations of conv layer `layer` for the last forward_planes batch."""
+        cout = self._n_filter if self.net_kind == "resnet" else weights.SIMPLE_LAYERS[layer][1]
+        out = np.empty((n, cout, self.board_height, self.board_width), dtype=np.float32)
+        self._ck(self.L.apz_layer_io(self._h, int(layer), as_ptr(out, C.c_float), out.size))
+        return out
+
+    def evaluate_codes(self, codes):
+        """codes uint8 [n, code_stride] (Board.position_codes / TreePool.advance) ->
+        (probs [n, HW], values [n]); planes are built on the GPU."""
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.code_stride)
+        n = c.shape[0]
+        probs = np.empty((n, self.hw), dtype=np.float32)
+        vals = np.empty(n, dtype=np.float32)
+        for s in range(0, n, self.batchsize):
+            k = min(self.batchsize, n - s)
+            self._ck(self.L.apz_forward_codes_host(self._h, as_ptr(c[s:s + k], C.c_uint8), k,
+                                                   as_ptr(probs[s:s + k], C.c_float),
+                                                   as_ptr(vals[s:s + k], C.c_float)))
+        return probs, vals
+
+    # ---- reference API
+    def policy_value(self, state_batch):
+        """Batched forward (policy_value_net_mxnet.py:232-242): -> (acts [B,HW], vals [B,1])."""
+        states = np.asarray(state_batch)
+        probs, vals = self.forward_planes(states.reshape(-1, self.channelnum, self.board_height, self.board_width))
+        return probs, vals.reshape(-1, 1)
+
+    def policy_value2(self, state_batch):
+        return self.policy_value(state_batch)
+
+    def policy_value_fn(self, board):
+        """(action, prob) pairs over the legal moves + value of the position for the player to
+        move (policy_value_net_mxnet.py:261-280): priors are NOT renormalised over legal moves."""
+        legal = board.availables
+        state = np.ascontiguousarray(board.current_state(), dtype=np.float32)
+        probs, vals = self.forward_planes(state.reshape(1, self.channelnum, self.board_height, self.board_width))
+        return zip(legal, probs[0][legal]), vals[0:1]
+
+    def train_step(self, *a, **k):
+        raise NotImplementedError("training is outside the hot path built here (SURVEY.md section 8f)")
+
+    # ---- measurement hooks
+    def conv_bench(self, layer, n, iters=100, warmup=20):
+        ms = np.zeros(1, dtype=np.float32)
+        self._ck(self.L.apz_conv3x3_bench(self._h, int(layer), int(n), int(iters), int(warmup), as_ptr(ms, C.c_float)))
+        return float(ms[0])
+
+    def set_profiling(self, on):
+        self._ck(self.L.apz_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_time_ms(self, kernel_class):
+        out = np.zeros(2, dtype=np.float32)
+        self._ck(self.L.apz_kernel_time_ms(self._h, KERNEL_CLASSES[kernel_class], as_ptr(out, C.c_float)))
+        return float(out[0]), int(out[1])
+
+    def sync(self):
+        self._ck(self.L.apz_sync(self._h))

@@ -1,0 +1,125 @@
+/*
+ * alphapig_hip.h -- C ABI of libalphapig_hip.so: the batched policy-value evaluator on
+ * hand-written gfx950 (MI355X / CDNA4) HIP kernels.
+ *
+ * Plain C: pointers and sizes only.  "dev" pointers are device (HBM) addresses, "host"
+ * pointers ordinary or pinned host memory.  One engine = one device + one HIP stream; an
+ * engine is not thread-safe.  int-returning calls return >= 0 on success, a negative
+ * APZ_E_* code on failure (text: apz_last_error()).  No exceptions cross the boundary.
+ *
+ * Reference interfaces replaced (file:line in the reference tree):
+ *   PolicyValueNet.__init__ / create_policy_value_predict / set_params
+ *                                   policy_value_net_mxnet.py:21-38, :214-230
+ *   network graph (stem, residual blocks, heads)      policy_value_net_mxnet.py:70-102
+ *                                                     policy_value_net_mxnet_simple.py:68-92
+ *   PolicyValueNet.policy_value (batched forward)     policy_value_net_mxnet.py:232-242
+ *   PolicyValueNet.policy_value_fn (H2D, forward, D2H) policy_value_net_mxnet.py:261-280
+ *   Board.current_state (plane encoding, done on device from compact codes) game.py:68-94
+ *   TrainPipeline.get_equi_data (8-fold dihedral augmentation) train_mxnet.py:115-135
+ */
+#ifndef ALPHAPIG_HIP_H
+#define ALPHAPIG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APZ_OK 0
+#define APZ_E_ARG (-1)
+#define APZ_E_HIP (-2)       /* a HIP runtime call failed                        */
+#define APZ_E_STATE (-3)     /* e.g. forward before weights were loaded           */
+#define APZ_E_UNSUPPORTED (-4)
+
+#define APZ_NET_RESNET 0     /* policy_value_net_mxnet.py        */
+#define APZ_NET_SIMPLE 1     /* policy_value_net_mxnet_simple.py */
+
+/* kernel classes for apz_kernel_time_ms */
+#define APZ_K_STEM 0
+#define APZ_K_TRUNK 1
+#define APZ_K_HEAD_CONV 2
+#define APZ_K_HEAD_FC 3
+#define APZ_K_ENCODE 4
+#define APZ_K_COUNT 5
+
+typedef struct apz_engine apz_engine;
+
+typedef struct apz_config {
+    int32_t height;     /* board_height                                                 */
+    int32_t width;      /* board_width                                                  */
+    int32_t c_in;       /* input planes: 9 (channelnum, policy_value_net_mxnet.py:24) or 4 */
+    int32_t n_filter;   /* trunk width (resnet), policy_value_net_mxnet.py:21           */
+    int32_t n_blocks;   /* residual blocks (resnet)                                     */
+    int32_t net_kind;   /* APZ_NET_*                                                    */
+    int32_t max_batch;  /* largest n accepted by forward calls                          */
+    int32_t device;     /* HIP device ordinal                                           */
+} apz_config;
+
+const char *apz_last_error(void);
+int apz_version(void);
+int apz_device_count(void);
+
+apz_engine *apz_create(const apz_config *cfg);
+void apz_destroy(apz_engine *e);
+
+/* Parameter table (MXNet names, policy_value_loss.json): name and element count. */
+int apz_param_count(apz_engine *e);
+const char *apz_param_name(apz_engine *e, int i);
+int64_t apz_param_size(apz_engine *e, int i);
+/* Load RAW parameters (conv weight/bias, BN gamma/beta/moving stats, FC weight/bias) from
+ * host float32 arrays; every table entry must be supplied.  BatchNorm (eps 1e-3,
+ * fix_gamma semantics per layer) is folded into conv weights/biases inside. */
+int apz_load_weights(apz_engine *e, const char *const *names, const float *const *host_ptrs,
+                     const int64_t *sizes, int n);
+
+/* Batched forward on the engine's stream, asynchronous.  planes_dev [n][c_in][H][W] f32.
+ * probs_dev [n][H*W], values_dev [n]; logits_dev / vlogits_dev (pre-softmax / pre-tanh)
+ * may be NULL. */
+int apz_forward(apz_engine *e, const void *planes_dev, int n, void *probs_dev, void *values_dev,
+                void *logits_dev, void *vlogits_dev);
+/* Host-buffer convenience (H2D, forward, D2H, sync): policy_value / policy_value_fn path. */
+int apz_forward_host(apz_engine *e, const float *planes_host, int n, float *probs_host,
+                     float *values_host);
+/* Self-play path: compact position codes (include/alphapig_host.h, apzh_code_stride bytes
+ * per leaf) H2D, planes encoded on device, forward, D2H, sync. */
+int apz_forward_codes_host(apz_engine *e, const uint8_t *codes_host, int n, float *probs_host,
+                           float *values_host);
+/* Asynchronous halves of the same, for overlapping host tree work with the GPU: buffers
+ * must be pinned (apz_host_alloc) and stay valid until apz_sync() returns. */
+int apz_forward_codes_async(apz_engine *e, const uint8_t *codes_pinned, int n, float *probs_pinned,
+                            float *values_pinned);
+void *apz_host_alloc(int64_t bytes);   /* pinned host memory */
+void apz_host_free(void *p);
+
+/* codes_dev [n][stride] u8 -> planes_dev [n][n_planes][H][W] f32 (n_planes 9 or 4). */
+int apz_encode_planes(apz_engine *e, const void *codes_dev, int n, int n_planes, void *planes_dev);
+/* 8-fold dihedral augmentation, reference order r1, r1f, r2, r2f, r3, r3f, id, idf:
+ * planes_dev [n][c][H][W], pi_dev [n][H*W] -> planes_out_dev [n*8][c][H][W], pi_out_dev [n*8][H*W]. */
+int apz_augment8(apz_engine *e, const void *planes_dev, const void *pi_dev, int n, int c,
+                 void *planes_out_dev, void *pi_out_dev);
+
+int apz_sync(apz_engine *e);
+void *apz_stream(apz_engine *e);
+void *apz_device_alloc(apz_engine *e, int64_t bytes);
+void apz_device_free(apz_engine *e, void *p);
+int apz_memcpy_h2d(apz_engine *e, void *dst_dev, const void *src_host, int64_t bytes);
+int apz_memcpy_d2h(apz_engine *e, void *dst_host, const void *src_dev, int64_t bytes);
+
+/* ---- measurement / test hooks ---------------------------------------------------------- */
+/* Time conv layer `layer` (0 = stem, 1.. = trunk convs in graph order) alone at batch n on
+ * synthetic resident inputs: `warmup` untimed + `iters` timed launches bracketed by HIP
+ * events on the engine stream; ms_out[0] = average milliseconds per launch. */
+int apz_conv3x3_bench(apz_engine *e, int layer, int n, int iters, int warmup, float *ms_out);
+/* After a forward of batch n: copy the output activation of conv layer `layer`
+ * ([n][C_out][H][W]) to host (per-layer parity tests). */
+int apz_layer_io(apz_engine *e, int layer, float *host_out, int64_t count);
+/* Per-kernel-class HIP-event timing over subsequent forwards: enable, then read
+ * out[0] = total ms, out[1] = launches since enabling (resolved at apz_sync). */
+int apz_set_profiling(apz_engine *e, int on);
+int apz_kernel_time_ms(apz_engine *e, int kernel_class, float *out2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,228 @@
+"""GPU parity tests (run with -m gpu on the MI355X): the HIP evaluator, through its C ABI,
+against the CPU oracle (oracle/net_ref.py, float64) on the same seeded inputs.
+
+Tolerance: 1e-4 absolute on pre-softmax policy logits and on the pre-tanh value (north_star),
+2e-5 on probabilities / values; exact for the integer kernels (plane encoding, augmentation).
+The net oracle itself is "parity unpinned" (MXNet absent) -- see oracle/__init__.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from alphapig_amd import weights
+from oracle import net_ref
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_ATOL = 1e-4
+
+
+def random_positions(n, w, c=9, seed=1234):
+    """SURVEY 8(d) synthetic leaves: k ~ U{0..80} stones, alternating colours, real encoder."""
+    from alphapig_amd.treepool import TreePool
+    rs = np.random.RandomState(seed)
+    pool = TreePool(w, w, 4 if w < 15 else 5, n_games=1, n_playout=1)
+    codes = []
+    for _ in range(n):
+        k = int(rs.randint(0, min(81, w * w)))
+        cells = rs.permutation(w * w)[:k]
+        pool.set_position(0, cells, [1 + (i % 2) for i in range(k)], 1 + (k % 2))
+        codes.append(pool.codes(0))
+    codes = np.stack(codes)
+    return codes, pool.codes_to_planes(codes, c)
+
+
+@pytest.fixture(scope="module")
+def resnet3():
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=5, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm)
+    yield net, prm
+    net.close()
+
+
+def test_library_exports_every_declared_symbol():
+    import re
+    from alphapig_amd import _native
+    L = _native.hip()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "alphapig_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(apz_[a-z0-9_]+)\s*\(", hdr)))
+    assert set(declared) == set(_native.HIP_SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s)
+    assert L.apz_device_count() >= 1
+
+
+def test_param_table_matches_python(resnet3):
+    net, prm = resnet3
+    table = net.param_table()
+    shapes = weights.param_shapes("resnet", 15, 15, 9, 3, 128)
+    assert [n for n, _ in table] == list(shapes.keys())
+    assert [s for _, s in table] == [int(np.prod(v)) for v in shapes.values()]
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 37, 64])
+def test_resnet_layers_and_heads(resnet3, n):
+    net, prm = resnet3
+    _, planes = random_positions(n, 15, seed=100 + n)
+    logits, probs, vlog, vals = net.forward_with_logits(planes)
+    o_logits, o_probs, o_vlog, o_vals, (o_stem, o_trunk) = net_ref.forward(prm, planes, "resnet", 3, np.float64, True)
+    np.testing.assert_allclose(logits, o_logits, rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(vlog, o_vlog[:, 0], rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(probs, o_probs, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(vals, o_vals[:, 0], rtol=0, atol=2e-5)
+    assert np.abs(probs.sum(axis=1) - 1).max() < 1e-5
+    # per-layer: stem and last trunk conv (needs the host-staged path so planes are resident)
+    p2, v2 = net.forward_planes(planes)
+    np.testing.assert_array_equal(p2, probs)
+    np.testing.assert_array_equal(v2, vals)
+    np.testing.assert_allclose(net.layer_output(0, n), o_stem, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(net.layer_output(6, n), o_trunk, rtol=0, atol=2e-4)
+
+
+def test_resnet_full_depth_10_blocks():
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=32, n_blocks=10, n_filter=128, model_params=prm)
+    _, planes = random_positions(24, 15, seed=7)
+    logits, probs, vlog, vals = net.forward_with_logits(planes)
+    o_logits, o_probs, o_vlog, o_vals = net_ref.forward(prm, planes, "resnet", 10, np.float64)
+    np.testing.assert_allclose(logits, o_logits, rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(vlog, o_vlog[:, 0], rtol=0, atol=LOGIT_ATOL)
+    # reference-style fresh init as well (unit BN stats, zero biases)
+    prm2 = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=3, style="reference")
+    net.set_params(prm2)
+    logits2 = net.forward_with_logits(planes)[0]
+    np.testing.assert_allclose(logits2, net_ref.forward(prm2, planes, "resnet", 10)[0], rtol=0, atol=LOGIT_ATOL)
+    net.close()
+
+
+def test_resnet_8x8_and_c_in_4():
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 8, 8, 9, 2, 128, seed=2, style="bench")
+    net = PolicyValueNet(8, 8, batch_size=32, n_blocks=2, n_filter=128, model_params=prm)
+    _, planes = random_positions(19, 8, seed=9)
+    logits = net.forward_with_logits(planes)[0]
+    np.testing.assert_allclose(logits, net_ref.forward(prm, planes, "resnet", 2)[0], rtol=0, atol=LOGIT_ATOL)
+    net.close()
+    # the north_star measurement shape: 4 input planes (game.py:96-115 encoder)
+    prm4 = weights.init_params("resnet", 15, 15, 4, 1, 128, seed=4, style="bench")
+    net4 = PolicyValueNet(15, 15, batch_size=32, n_blocks=1, n_filter=128, model_params=prm4, c_in=4)
+    _, planes4 = random_positions(21, 15, c=4, seed=11)
+    logits4 = net4.forward_with_logits(planes4)[0]
+    np.testing.assert_allclose(logits4, net_ref.forward(prm4, planes4, "resnet", 1)[0], rtol=0, atol=LOGIT_ATOL)
+    net4.close()
+
+
+def test_simple_net_8x8_config2():
+    """BASELINE config 2 evaluator: policy_value_net_mxnet_simple on 8x8."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("simple", 8, 8, 9, seed=6, style="bench")
+    net = PolicyValueNet(8, 8, batch_size=64, model_params=prm, net_kind="simple")
+    _, planes = random_positions(64, 8, seed=13)
+    logits, probs, vlog, vals = net.forward_with_logits(planes)
+    o = net_ref.forward(prm, planes, "simple", dtype=np.float64, return_trunk=True)
+    np.testing.assert_allclose(logits, o[0], rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(vlog, o[2][:, 0], rtol=0, atol=LOGIT_ATOL)
+    net.forward_planes(planes)
+    np.testing.assert_allclose(net.layer_output(0, 64), o[4][0], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(net.layer_output(5, 64), o[4][1], rtol=0, atol=1e-4)
+    net.close()
+
+
+def test_simple_net_15x15():
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("simple", 15, 15, 9, seed=8, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=16, model_params=prm, net_kind="simple")
+    _, planes = random_positions(9, 15, seed=17)
+    logits = net.forward_with_logits(planes)[0]
+    np.testing.assert_allclose(logits, net_ref.forward(prm, planes, "simple")[0], rtol=0, atol=LOGIT_ATOL)
+    net.close()
+
+
+def test_encode_planes_on_device_matches_golden(resnet3, golden_dir):
+    """codes -> planes on the GPU is the same integer map as Board.current_state."""
+    net, prm = resnet3
+    codes, planes = random_positions(40, 15, seed=21)
+    p_codes, v_codes = net.evaluate_codes(codes)
+    p_planes, v_planes = net.forward_planes(planes)
+    np.testing.assert_array_equal(p_codes, p_planes)
+    np.testing.assert_array_equal(v_codes, v_planes)
+    # and against planes the reference itself produced
+    from alphapig_amd.game import Board
+    g = np.load(os.path.join(golden_dir, "planes.npz"))
+    bc, bp = [], []
+    for k in range(int(g["n_cases"])):
+        w, n, sp, _ = [int(x) for x in g["c%d_meta" % k]]
+        if w != 15:
+            continue
+        b = Board(width=w, height=w, n_in_row=n)
+        b.init_board(sp)
+        for m in g["c%d_moves" % k]:
+            b.do_move(int(m))
+        bc.append(b.position_codes())
+        bp.append(g["c%d_planes" % k].astype(np.float32))
+    pa, va = net.evaluate_codes(np.stack(bc))
+    pb, vb = net.forward_planes(np.stack(bp))
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(va, vb)
+
+
+def test_policy_value_fn_contract(resnet3):
+    """Types of the reference boundary (policy_value_net_mxnet.py:274-280)."""
+    net, prm = resnet3
+    from alphapig_amd.game import Board
+    b = Board(width=15, height=15, n_in_row=5)
+    b.init_board()
+    for m in (112, 113, 97):
+        b.do_move(m)
+    pairs, v = net.policy_value_fn(b)
+    pairs = list(pairs)
+    assert [a for a, _ in pairs] == b.availables
+    assert all(isinstance(p, np.float32) for _, p in pairs)
+    assert isinstance(v, np.ndarray) and v.shape == (1,) and v.dtype == np.float32
+    acts, vals = net.policy_value(np.stack([np.ascontiguousarray(b.current_state())] * 3))
+    assert acts.shape == (3, 225) and vals.shape == (3, 1) and acts.dtype == np.float32
+    ref = net_ref.forward(prm, np.ascontiguousarray(b.current_state())[None], "resnet", 3)
+    np.testing.assert_allclose(np.array([p for _, p in pairs]), ref[1][0][b.availables], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(v, ref[3][0], rtol=0, atol=2e-5)
+
+
+def test_batch_larger_than_max_and_errors(resnet3):
+    net, prm = resnet3
+    _, planes = random_positions(150, 15, seed=31)     # > batch_size 64: chunked
+    p, v = net.forward_planes(planes)
+    p1, v1 = net.forward_planes(planes[100:101])
+    np.testing.assert_array_equal(p[100], p1[0])
+    with pytest.raises(ValueError):
+        net.forward_planes(np.zeros((2, 9, 8, 8), np.float32))
+    from alphapig_amd.policy_value_net import EvaluatorError, PolicyValueNet
+    with pytest.raises(EvaluatorError):
+        PolicyValueNet(10, 10, batch_size=4, n_blocks=1)
+    bad = dict(prm)
+    del bad["bnA1_gamma"]
+    with pytest.raises(EvaluatorError):
+        net.set_params(bad)
+
+
+def test_augment8_matches_reference_tables(resnet3, golden_dir):
+    import ctypes as C
+    net, prm = resnet3
+    g = np.load(os.path.join(golden_dir, "equi.npz"))
+    k = [i for i in range(int(g["n"])) if int(g["e%d_w" % i]) == 15][0]
+    state = np.arange(9 * 225, dtype=np.float32).reshape(1, 9, 15, 15)
+    pi = np.arange(225, dtype=np.float32).reshape(1, 225)
+    L, h = net.L, net._h
+    d = [L.apz_device_alloc(h, x) for x in (state.nbytes, pi.nbytes, state.nbytes * 8, pi.nbytes * 8)]
+    L.apz_memcpy_h2d(h, d[0], state.ctypes.data, state.nbytes)
+    L.apz_memcpy_h2d(h, d[1], pi.ctypes.data, pi.nbytes)
+    assert L.apz_augment8(h, d[0], d[1], 1, 9, d[2], d[3]) == 0
+    so = np.empty((8, 9, 15, 15), np.float32)
+    po = np.empty((8, 225), np.float32)
+    L.apz_memcpy_d2h(h, so.ctypes.data, d[2], so.nbytes)
+    L.apz_memcpy_d2h(h, po.ctypes.data, d[3], po.nbytes)
+    for x in d:
+        L.apz_device_free(h, x)
+    np.testing.assert_array_equal(so.astype(np.int32), g["e%d_state_perm" % k])
+    np.testing.assert_array_equal(po.astype(np.int32), g["e%d_pi_perm" % k])
