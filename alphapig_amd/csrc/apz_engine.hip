@@ -210,7 +210,10 @@ void resolve_pending(apz_engine* e) {
 template <int H, int W, int CT>
 int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
     using G = apz::ConvGeo<H, W>;
-    const int lds = G::lds_bytes(L.cin_pad);
+    // keep channel chunks a power-of-two-ish split of Cin: 256 ch at 15x15 -> 2 x 128
+    int cchunk = L.cin_pad;
+    while (cchunk > G::max_chunk()) cchunk = ((cchunk / 2) + 3) & ~3;
+    const int lds = G::lds_bytes(cchunk);
     static int configured_lds = -1;
     auto kern = apz::conv3x3_mfma_kernel<H, W, CT>;
     if (lds > configured_lds) {
@@ -221,7 +224,7 @@ int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const floa
     int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(lds, 1)));
     int grid = std::min(n, e->num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, resid, out, n, L.cin,
-                       L.cin_pad, 1);
+                       L.cin_pad, cchunk, 1);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }

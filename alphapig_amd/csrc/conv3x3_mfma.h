@@ -43,7 +43,9 @@ struct ConvGeo {
     static constexpr int SLACK = 64;                        // floats; over-reads of dead lanes
     static_assert(W <= 15 && H <= 16, "tile mapping assumes W <= 15");
     static_assert(PS >= PLANE && PS % 32 == 16, "plane stride");
-    static int lds_bytes(int cin_pad) { return (cin_pad * PS + SLACK) * (int)sizeof(float); }
+    static int lds_bytes(int cchunk) { return (cchunk * PS + SLACK) * (int)sizeof(float); }
+    // largest multiple-of-4 channel count whose tile fits the 160 KiB LDS
+    static int max_chunk() { return ((160 * 1024 / (int)sizeof(float) - SLACK) / PS) & ~3; }
 };
 
 // wpk layout: [Cout/16][Cin_pad/4][9][64]  (see pack_conv3x3 in apz_engine.hip)
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ resid,
                                                            float* __restrict__ out, int n, int cin,
-                                                           int cin_pad, int relu) {
+                                                           int cin_pad, int cchunk, int relu) {
     using G = ConvGeo<H, W>;
     constexpr int HW = H * W;
     extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     const int j = lane & 15;          // pixel lane
     const int cout = 64 * CT;
     const int n4 = cin_pad >> 2;
-    const int lds_floats = cin_pad * G::PS + G::SLACK;
+    const int lds_floats = cchunk * G::PS + G::SLACK;   // cchunk: channels resident at once
 
     // zero the whole tile once: pads / halo rows / padded channels are never written again
     for (int i = tid * 4; i < lds_floats; i += 256 * 4) {
@@ -76,71 +78,83 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     const int px = j % G::WT, prow = j / G::WT;
 
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
-        __syncthreads();   // previous board fully consumed (and the zero fill done)
-        // ---- stage the board: dense [cin][H][W] -> padded LDS tile
-        {
-            const float* src = in + (size_t)b * cin * HW;
-            const int total = cin * HW;
-            const int total4 = total & ~3;
-            for (int e = tid * 4; e < total4; e += 256 * 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src + e);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int idx = e + u;
-                    const int c = idx / HW, rem = idx - c * HW;
-                    const int y = rem / W, x = rem - y * W;
-                    tile[c * G::PS + (y + 1) * G::RS + x + 1] = v[u];
-                }
-            }
-            for (int idx = total4 + tid; idx < total; idx += 256) {
-                const int c = idx / HW, rem = idx - c * HW;
-                const int y = rem / W, x = rem - y * W;
-                tile[c * G::PS + (y + 1) * G::RS + x + 1] = src[idx];
-            }
-        }
-        __syncthreads();
-
         f32x4 acc[CT][G::NT];
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
             for (int t = 0; t < G::NT; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // A fragments of this wave's CT channel tiles, double-buffered over ci4
-        const float* wbase = wpk + ((size_t)(wave * CT) * n4 * 9) * 64 + lane;
-        float a_cur[CT][9], a_nxt[CT][9];
+        // channel chunks: all of Cin when it fits LDS (<=128 ch at 15x15), else 2+ passes
+        for (int c0 = 0; c0 < cin_pad; c0 += cchunk) {
+            __syncthreads();   // previous chunk / board fully consumed (and the zero fill done)
+            // ---- stage channels [c0, c0+cchunk) of the board: dense [cin][H][W] -> padded LDS tile
+            {
+                const int cn = min(cchunk, cin - c0);
+                const float* src = in + ((size_t)b * cin + c0) * HW;
+                const int total = cn * HW;
+                const int head = (int)((4 - ((((size_t)b * cin + c0) * HW) & 3)) & 3);   // to 16-B alignment
+                for (int idx = tid; idx < min(head, total); idx += 256) {
+                    const int c = idx / HW, rem = idx - c * HW;
+                    const int y = rem / W, x = rem - y * W;
+                    tile[c * G::PS + (y + 1) * G::RS + x + 1] = src[idx];
+                }
+                const int body4 = (total > head) ? ((total - head) & ~3) : 0;
+                for (int e = tid * 4; e < body4; e += 256 * 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + head + e);
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-            for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = wbase[((size_t)ct * n4 * 9 + tap) * 64];
+                    for (int u = 0; u < 4; u++) {
+                        const int idx = head + e + u;
+                        const int c = idx / HW, rem = idx - c * HW;
+                        const int y = rem / W, x = rem - y * W;
+                        tile[c * G::PS + (y + 1) * G::RS + x + 1] = v[u];
+                    }
+                }
+                for (int idx = head + body4 + tid; idx < total; idx += 256) {
+                    const int c = idx / HW, rem = idx - c * HW;
+                    const int y = rem / W, x = rem - y * W;
+                    tile[c * G::PS + (y + 1) * G::RS + x + 1] = src[idx];
+                }
+            }
+            __syncthreads();
 
-        const float* bptr = tile + lane_off;
-        for (int c4 = 0; c4 < n4; c4++) {
-            const int c4n = (c4 + 1 < n4) ? c4 + 1 : c4;
+            // A fragments of this wave's CT channel tiles, double-buffered over ci4
+            const int c4_lo = c0 >> 2, c4_hi = min(cin_pad, c0 + cchunk) >> 2;
+            const float* wbase = wpk + ((size_t)(wave * CT) * n4 * 9) * 64 + lane;
+            float a_cur[CT][9], a_nxt[CT][9];
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                 for (int tap = 0; tap < 9; tap++)
-                    a_nxt[ct][tap] = wbase[(((size_t)ct * n4 + c4n) * 9 + tap) * 64];
+                    a_cur[ct][tap] = wbase[(((size_t)ct * n4 + c4_lo) * 9 + tap) * 64];
+
+            const float* bptr = tile + lane_off;
+            for (int c4 = c4_lo; c4 < c4_hi; c4++) {
+                const int c4n = (c4 + 1 < c4_hi) ? c4 + 1 : c4;
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                float r[G::NFRAG];
+                for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-                for (int f = 0; f < G::NFRAG; f++) r[f] = bptr[f * G::RS + kx];
+                    for (int tap = 0; tap < 9; tap++)
+                        a_nxt[ct][tap] = wbase[(((size_t)ct * n4 + c4n) * 9 + tap) * 64];
 #pragma unroll
-                for (int ky = 0; ky < 3; ky++)
+                for (int kx = 0; kx < 3; kx++) {
+                    float r[G::NFRAG];
 #pragma unroll
-                    for (int t = 0; t < G::NT; t++)
+                    for (int f = 0; f < G::NFRAG; f++) r[f] = bptr[f * G::RS + kx];
 #pragma unroll
-                        for (int ct = 0; ct < CT; ct++)
-                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ct][ky * 3 + kx],
-                                                                              r[t * G::RPT + ky], acc[ct][t], 0, 0, 0);
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int t = 0; t < G::NT; t++)
+#pragma unroll
+                            for (int ct = 0; ct < CT; ct++)
+                                acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    a_cur[ct][ky * 3 + kx], r[t * G::RPT + ky], acc[ct][t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                    for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = a_nxt[ct][tap];
+                bptr += 4 * G::PS;
             }
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-                for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = a_nxt[ct][tap];
-            bptr += 4 * G::PS;
         }
 
         // ---- epilogue: + folded bias (+ residual), ReLU, dense NCHW store
