@@ -74,7 +74,7 @@ def build_oracle(force=False):
     os.makedirs(os.path.dirname(ORACLE_LIB), exist_ok=True)
     if not force and _newer(ORACLE_LIB, [src]):
         return ORACLE_LIB
-    _run(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", src, "-lm", "-o", ORACLE_LIB])
+    _run(["gcc", "-O3", "-mavx2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", src, "-lm", "-o", ORACLE_LIB])
     return ORACLE_LIB
 
 

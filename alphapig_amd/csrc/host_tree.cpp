@@ -682,7 +682,7 @@ int apzh_root_visits_dense(apzh_pool *p, const int32_t *games, int n, int32_t *v
         Game &g = p->games[games[i]];
         Arena &t = g.tree[g.cur];
         int32_t *row = visits + (size_t)i * hw;
-        std::fill(row, row + hw, 0);
+        std::fill(row, row + hw, -1);
         int nc = t.first_child[0] >= 0 ? t.n_child[0] : 0;
         for (int k = 0; k < nc; k++) row[t.action[t.first_child[0] + k]] = t.n[t.first_child[0] + k];
         if (n_children) n_children[i] = nc;

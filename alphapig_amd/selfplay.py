@@ -1,0 +1,238 @@
+"""SelfPlayEngine: G concurrent self-play games, ONE coalesced leaf batch per step.
+
+Each game slot runs exactly the reference episode (Game_AI.start_self_play, reference
+game_ai.py:70-139: 9 % forced two-ply opening, get_action(temp, return_prob=1) per ply,
+z assignment) with the reference search (mcts_alphaZero.py:141-218: n_playout sequential
+playouts, visit-count softmax, Dirichlet(0.3) mixed into the sampling distribution, subtree
+reuse).  The reference evaluates one leaf per forward; here every game keeps at
+most one leaf in flight, so the G pending leaves of a step form one contiguous batch for the
+HIP evaluator while every game's tree stays bit-identical to a sequential run.
+
+Game k (global index) draws from np.random.RandomState(base_seed + k) and
+random.Random(base_seed + k): the same streams as `np.random.seed` / `random.seed` in a
+sequential reference run of that game.
+
+Host/GPU overlap: the slots are split into `pipeline` groups; while the evaluator works on one
+group's leaves (in a worker thread -- ctypes releases the GIL) the native tree pool advances the
+next group.
+"""
+import collections
+import random as _random
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from .game_ai import draw_forced_opening, one_hot_pi
+from .treepool import TreePool, NEED_EVAL, MOVE_READY
+
+Episode = collections.namedtuple("Episode", "index moves movers codes pis zs winner")
+
+
+class PlanesEvaluator(object):
+    """Adapter: wraps `fn(planes[n,9,H,W] float32) -> (probs[n,HW], values[n])` as an evaluator
+    with evaluate_codes().  Used for CPU tests of the scheduler with a stand-in network."""
+
+    def __init__(self, fn, pool):
+        self._fn, self._pool = fn, pool
+
+    def evaluate_codes(self, codes):
+        p, v = self._fn(self._pool.codes_to_planes(codes, 9))
+        return np.ascontiguousarray(p, dtype=np.float32), np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
+
+
+class _Slot(object):
+    __slots__ = ("index", "rng", "pyrnd", "codes", "pis", "movers", "active")
+
+    def __init__(self):
+        self.active = False
+
+
+class SelfPlayEngine(object):
+    def __init__(self, evaluator, board_width=15, board_height=15, n_in_row=5, n_games=1024, n_playout=400,
+                 c_puct=5, temp=1.0, base_seed=0, n_threads=0, pipeline=2, noise_alpha=0.3, noise_eps=0.25,
+                 forced_opening=True, index_offset=0, index_stride=1):
+        self.pool = TreePool(board_width, board_height, n_in_row, n_games=n_games, n_playout=n_playout,
+                             c_puct=c_puct, prior_is_f32=True, n_threads=n_threads)
+        self.evaluator = evaluator if hasattr(evaluator, "evaluate_codes") else PlanesEvaluator(evaluator, self.pool)
+        self.G, self.hw = int(n_games), board_width * board_height
+        self.n_playout, self.temp = int(n_playout), temp
+        self.base_seed = int(base_seed)
+        self.noise_alpha, self.noise_eps = noise_alpha, noise_eps
+        self.forced_opening = forced_opening
+        self.pipeline = max(1, int(pipeline))
+        # multi-GPU sharding: this engine owns global games offset, offset+stride, ... (dist.py)
+        self.index_offset, self.index_stride = int(index_offset), int(index_stride)
+        self.slots = [_Slot() for _ in range(self.G)]
+        self.next_index = 0
+        self.finished = []
+        self.stats = collections.Counter()
+        self.timers = collections.Counter()
+        self._limit = None
+        self._exec = ThreadPoolExecutor(max_workers=1) if self.pipeline > 1 else None
+
+    # ---- slot life cycle -------------------------------------------------------------------
+    def _start_game(self, s):
+        slot = self.slots[s]
+        if self._limit is not None and self.next_index >= self._limit:
+            slot.active = False
+            return False
+        k = self.index_offset + self.next_index * self.index_stride     # global game index
+        self.next_index += 1
+        slot.index = k
+        slot.rng = np.random.RandomState(self.base_seed + k)
+        slot.pyrnd = _random.Random(self.base_seed + k)
+        slot.codes, slot.pis, slot.movers = [], [], []
+        slot.active = True
+        self.pool.reset(s, 0)
+        forced = draw_forced_opening(slot.pyrnd) if self.forced_opening else None
+        if forced is not None:
+            for mv in forced:
+                self._record(s, one_hot_pi(self.hw, mv))
+                self.pool.play_move(s, mv)
+            self.stats["forced_openings"] += 1
+        return True
+
+    def _record(self, s, pi):
+        slot = self.slots[s]
+        slot.codes.append(self.pool.codes(s))
+        slot.pis.append(pi)
+        slot.movers.append(self.pool.status(s)[0])
+
+    def _finish_game(self, s, winner):
+        slot = self.slots[s]
+        movers = np.array(slot.movers)
+        z = np.zeros(len(movers))
+        if winner != -1:
+            z[movers == winner] = 1.0
+            z[movers != winner] = -1.0
+        moves, _ = self.pool.history(s)
+        self.finished.append(Episode(slot.index, moves.astype(np.int32), movers.astype(np.int8),
+                                     np.stack(slot.codes), np.stack(slot.pis), z, winner))
+        self.stats["games"] += 1
+        self.stats["plies"] += len(movers)
+
+    # ---- one move of every MOVE_READY slot (mcts_alphaZero.py:151-157, :187-203) ------------
+    def _play_ready(self, ready):
+        visits, _ = self.pool.root_visits_dense(ready)
+        for row, s in zip(visits, ready):
+            s = int(s)
+            slot = self.slots[s]
+            acts = np.flatnonzero(row >= 0)
+            x = 1.0 / self.temp * np.log(row[acts].astype(np.int64) + 1e-10)
+            probs = np.exp(x - np.max(x))
+            probs /= np.sum(probs)
+            pi = np.zeros(self.hw)
+            pi[acts] = probs
+            noise = slot.rng.dirichlet(self.noise_alpha * np.ones(len(probs)))
+            move = int(slot.rng.choice(acts, p=(1.0 - self.noise_eps) * probs + self.noise_eps * noise))
+            self._record(s, pi)
+            ended, winner, _ = self.pool.play_move(s, move)
+            self.stats["moves"] += 1
+            if ended:
+                self._finish_game(s, winner)
+                self._start_game(s)
+
+    # ---- scheduling ------------------------------------------------------------------------
+    def _advance_group(self, ids):
+        """Advance the slots in `ids` until each one waits for an evaluation (or went idle).
+        -> (eval_ids, eval_codes)"""
+        t0 = time.perf_counter()
+        ids = np.array([s for s in ids if self.slots[s].active], dtype=np.int32)
+        eval_ids, eval_codes = [], []
+        while len(ids):
+            st, codes = self.pool.advance(ids)
+            need = st == NEED_EVAL
+            if need.any():
+                eval_ids.append(ids[need])
+                eval_codes.append(codes[need])
+            ready = ids[st == MOVE_READY]
+            if len(ready) == 0:
+                break
+            t1 = time.perf_counter()
+            self._play_ready(ready)
+            self.timers["moves_s"] += time.perf_counter() - t1
+            ids = np.array([s for s in ready if self.slots[s].active], dtype=np.int32)
+        self.timers["host_s"] += time.perf_counter() - t0
+        if not eval_ids:
+            return np.zeros(0, np.int32), np.zeros((0, self.pool.code_stride), np.uint8)
+        return np.concatenate(eval_ids), np.concatenate(eval_codes)
+
+    def _evaluate(self, codes):
+        t0 = time.perf_counter()
+        out = self.evaluator.evaluate_codes(codes)
+        self.timers["eval_s"] += time.perf_counter() - t0
+        return out
+
+    def _groups(self):
+        return [list(range(g, self.G, self.pipeline)) for g in range(self.pipeline)]
+
+    def run_steps(self, n_steps, total_games=None):
+        """Run n_steps scheduler rounds; in one round every active slot gets exactly one leaf
+        evaluated (terminal-leaf playouts and move selection ride along on the host).  Slots are
+        (re)seeded with fresh games until `total_games` have been started (None = unlimited).
+        -> number of leaf evaluations done."""
+        self._limit = total_games
+        for s in range(self.G):
+            if not self.slots[s].active:
+                self._start_game(s)
+        leafs = 0
+        groups = self._groups()
+        inflight = {}
+        for _ in range(n_steps):
+            busy = False
+            for gi, grp in enumerate(groups):
+                if gi in inflight:                       # finish this group's previous evaluation
+                    ids, fut = inflight.pop(gi)
+                    p, v = fut.result() if self._exec is not None else fut
+                    t0 = time.perf_counter()
+                    self.pool.feed(ids, p, v)
+                    self.timers["host_s"] += time.perf_counter() - t0
+                    leafs += len(ids)
+                ids, codes = self._advance_group(grp)    # overlaps the other groups' evaluations
+                if len(ids):
+                    busy = True
+                    inflight[gi] = (ids, self._exec.submit(self._evaluate, codes) if self._exec is not None
+                                    else self._evaluate(codes))
+            if not busy:
+                break
+        for gi in sorted(inflight):
+            ids, fut = inflight[gi]
+            p, v = fut.result() if self._exec is not None else fut
+            self.pool.feed(ids, p, v)
+            leafs += len(ids)
+        self.stats["leaf_evals"] += leafs
+        self.stats["rounds"] += n_steps
+        return leafs
+
+    def play_games(self, total_games, max_steps=None):
+        """Play `total_games` complete episodes -> list[Episode] ordered by game index."""
+        steps = 0
+        while self.stats["games"] < total_games:
+            n = self.run_steps(64, total_games)
+            steps += 64
+            if n == 0 and not any(s.active for s in self.slots):
+                break
+            if max_steps is not None and steps >= max_steps:
+                break
+        out = sorted(self.finished, key=lambda e: e.index)
+        return out
+
+    def terminal_playouts(self):
+        return sum(self.pool.stats(s)["terminal_playouts"] for s in range(self.G))
+
+    def close(self):
+        if self._exec is not None:
+            self._exec.shutdown(wait=True)
+            self._exec = None
+        self.pool.close()
+
+
+def episodes_to_tuples(episodes, pool):
+    """Flatten episodes to training tuples (state planes float32 [T,9,H,W], pi [T,HW], z [T])
+    -- the (s, pi, z) triples of game_ai.py:139."""
+    codes = np.concatenate([e.codes for e in episodes])
+    pis = np.concatenate([e.pis for e in episodes])
+    zs = np.concatenate([e.zs for e in episodes])
+    return pool.codes_to_planes(codes, 9), pis, zs

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play throughput of the batched MI355X engine (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]; configs[3] = the same per GPU sharded over 8): 15x15 board,
+5-in-row, n_playout=400, c_puct=5, temp=1.0, Dirichlet 0.3/0.25, 10-block / 128-filter residual
+net (random 'bench' init, synthetic: there are no published weights), 1024 concurrent games per
+GPU.  One "step" = one pass of the hot path over one batch: every one of the 1024 games runs
+select -> (leaf) -> expand/backup for one playout and the 1024 leaves are evaluated on the GPU
+(in `pipeline` coalesced sub-batches so host tree work overlaps the kernels).
+
+Reported `value` = self-play games/s = (playouts completed in the timed region / n_playout)
+plies / (mean plies per game) / seconds, aggregated over ranks (weak scaling: 1024 games per
+GPU).  Mean plies per game is a property of the workload, measured by playing complete games
+with this exact configuration (`--full-games`, result cached in profiles/calibration_r01.json);
+`leaf_evals_per_s` (directly counted) is printed alongside.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = trunk 3x3 conv, fp32 matrix pipe),
+`roofline_stem` (north_star's HBM target shape 8192x4x15x15 and the real C_in=9 stem),
+`cpu_baseline` (sequential CPU oracle port, 1 core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from alphapig_amd import dist, weights  # noqa: E402
+
+H = W = 15
+N_IN_ROW = 5
+N_PLAYOUT = 400
+N_BLOCKS = 10
+N_FILTER = 128
+GAMES_PER_GPU = 1024
+CALIB = os.path.join(REPO, "profiles", "calibration_r01.json")
+FP32_MATRIX_PEAK_TF = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def trunk_flops(batch):
+    return 2.0 * batch * N_FILTER * N_FILTER * 9 * H * W
+
+
+def load_mean_plies():
+    if os.path.exists(CALIB):
+        with open(CALIB) as f:
+            c = json.load(f)
+        return float(c["mean_plies_per_game"]), "profiles/calibration_r01.json (%d complete games, MI355X)" % c["games"]
+    return None, None
+
+
+def cpu_baseline(mean_plies, budget_s=15.0):
+    """Sequential oracle (scalar tree, one batch-1 forward per playout) on ONE host core."""
+    import random
+    from oracle.board_ref import RefBoard
+    from oracle.mcts_ref import RefMCTS
+    from oracle.net_ref_c import CNet
+    prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
+    net = CNet(prm, H, W, 9, N_FILTER, N_BLOCKS)
+    b = RefBoard(W, H, N_IN_ROW)
+    b.init_board()
+    mcts = RefMCTS(net.policy_value_fn, c_puct=5, n_playout=N_PLAYOUT)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        mcts.playout(b.clone())
+        n += 1
+    dt = time.perf_counter() - t0
+    leaf_s = n / dt
+    return {"value": leaf_s / (N_PLAYOUT * mean_plies), "unit": "games/s", "cores": 1, "kind": "port",
+            "leaf_evals_per_s": leaf_s,
+            "sample": "%d sequential playouts of one 15x15 game (oracle tree + oracle/net_ref.c batch-1 forward), "
+                      "%.1f s on 1 core; games/s = leaf-evals/s / (400 * mean plies)" % (n, dt)}
+
+
+def stem_roofline(device):
+    """north_star target kernel: batched stem conv at 8192 x C_in x 15 x 15 (HBM-bound shape)."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from kernel_bench import synth
+    out = {}
+    n = 8192
+    for c_in in (4, 9):
+        prm = weights.init_params("resnet", H, W, c_in, 1, N_FILTER, seed=0, style="bench")
+        net = PolicyValueNet(W, H, batch_size=n, n_blocks=1, n_filter=N_FILTER, model_params=prm, c_in=c_in,
+                             device=device)
+        _, planes = synth(n, W, c_in)
+        net.forward_planes(planes)
+        ms = net.conv_bench(0, n, iters=50, warmup=10)
+        alg = n * (c_in * H * W + N_FILTER * H * W) * 4 + N_FILTER * c_in * 9 * 4
+        out["c_in_%d" % c_in] = {"bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "us_per_launch": ms * 1e3,
+                                 "shape": "%dx%dx15x15 -> 128 ch" % (n, c_in), "algorithmic_bytes": alg,
+                                 "tflops": 2.0 * n * c_in * 9 * N_FILTER * H * W / ms / 1e9}
+        net.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
+    ap.add_argument("--pipeline", type=int, default=2)
+    ap.add_argument("--full-games", type=int, default=0, help="play this many COMPLETE games per GPU "
+                    "instead of timing --steps (measures games/s and mean plies directly; minutes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
+    args = ap.parse_args()
+
+    rank, world, local = dist.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    from alphapig_amd.selfplay import SelfPlayEngine
+
+    ncpu = os.cpu_count() or 1
+    threads = max(1, ncpu // max(world, 1))
+    G = args.games
+    prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
+    net = PolicyValueNet(W, H, batch_size=G, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, device=local)
+    eng = SelfPlayEngine(net, W, H, N_IN_ROW, n_games=G, n_playout=N_PLAYOUT, c_puct=5, temp=1.0, base_seed=20260000,
+                         n_threads=threads, pipeline=args.pipeline, index_offset=rank, index_stride=world)
+
+    def playouts_done():
+        return eng.stats["leaf_evals"] + eng.terminal_playouts()
+
+    mean_plies, plies_src = load_mean_plies()
+    if args.full_games:
+        dist.barrier()
+        net.sync()
+        t0 = time.perf_counter()
+        eps = eng.play_games(args.full_games)
+        net.sync()
+        dist.barrier()
+        dt = dist.all_reduce_max(time.perf_counter() - t0)
+        games = dist.all_reduce_sum(eng.stats["games"])
+        plies = dist.all_reduce_sum(eng.stats["plies"])
+        leafs = dist.all_reduce_sum(eng.stats["leaf_evals"])
+        # note: games still in flight when the target was reached are not counted (conservative)
+        if rank == 0:
+            res = {"mode": "full-games", "games": int(games), "mean_plies_per_game": plies / games,
+                   "seconds": dt, "games_per_s_completed_only": games / dt, "leaf_evals_per_s": leafs / dt,
+                   "leaf_evals": int(leafs), "n_gpus": world, "games_per_gpu_concurrent": G,
+                   "winners": {str(k): int(sum(1 for e in eps if e.winner == k)) for k in (-1, 1, 2)}}
+            print(json.dumps(res))
+        eng.close()
+        net.close()
+        return
+    if mean_plies is None:
+        raise SystemExit("profiles/calibration_r01.json missing: run `python bench.py --full-games 1024` once")
+
+    eng.run_steps(args.warmup)                       # W untimed warm-up steps
+    net.set_profiling(True)
+    p0, l0 = playouts_done(), eng.stats["leaf_evals"]
+    host0, eval0 = eng.timers["host_s"], eng.timers["eval_s"]
+    dist.barrier()
+    net.sync()
+    t0 = time.perf_counter()
+    eng.run_steps(args.steps)                        # exactly K timed steps
+    # the round's exchange: all-gather of the tuples of games that finished inside the window
+    done = [e for e in eng.finished]
+    if world > 1:
+        if done:
+            codes = np.concatenate([e.codes for e in done])
+            pis = np.concatenate([e.pis for e in done]).astype(np.float32)
+            zs = np.concatenate([e.zs for e in done]).astype(np.float32)
+        else:
+            codes = np.zeros((0, eng.pool.code_stride), np.uint8)
+            pis = np.zeros((0, H * W), np.float32)
+            zs = np.zeros(0, np.float32)
+        dist.all_gather_tuples(codes, pis, zs)
+    net.sync()
+    dist.barrier()
+    dt_local = time.perf_counter() - t0
+    dt = dist.all_reduce_max(dt_local)
+    playouts = dist.all_reduce_sum(playouts_done() - p0)
+    leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0)
+    trunk_ms, trunk_cnt = net.kernel_time_ms("trunk")
+    net.set_profiling(False)
+    if rank != 0:
+        eng.close()
+        net.close()
+        return
+
+    games_per_s = playouts / N_PLAYOUT / mean_plies / dt
+    batch = G // args.pipeline
+    trunk_avg_ms = trunk_ms / max(trunk_cnt, 1)
+    achieved_tf = trunk_flops(batch) / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
+    line = {
+        "metric": "self-play games/sec (15x15, n_playout=400)", "value": games_per_s, "unit": "games/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: 15x15, 5-in-row, n_playout=400, c_puct=5, temp=1.0, "
+                               "10-block/128-filter residual net, %d concurrent games per GPU" % G,
+                   "games_per_gpu": G, "leaf_batch": batch, "pipeline": args.pipeline, "host_threads": threads,
+                   "mean_plies_per_game": mean_plies, "mean_plies_source": plies_src, "weights": "random init seed 0"},
+        "leaf_evals_per_s": leafs / dt,
+        "playouts_per_s": playouts / dt,
+        "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
+        "roofline": {"kernel": "conv3x3_mfma_kernel<15,15,2> (trunk 128->128 3x3 + BN + residual + ReLU)",
+                     "bound": "mfma", "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": (achieved_tf / FP32_MATRIX_PEAK_TF) if achieved_tf else None, "traffic": None,
+                     "us_per_launch": trunk_avg_ms * 1e3, "launches": trunk_cnt,
+                     "flops_per_launch": trunk_flops(batch), "boards_per_launch": batch},
+    }
+    eng.close()
+    net.close()
+    if not args.no_extras and world == 1:
+        line["roofline_stem"] = stem_roofline(local)
+        line["cpu_baseline"] = cpu_baseline(mean_plies)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

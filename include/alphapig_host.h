@@ -118,7 +118,8 @@ int apzh_node_children(apzh_pool *p, int g, int node, int32_t *acts, int64_t *vi
                        double *node_q);
 /* 1: priors are float32 and c_puct*P is a float32 product; 0: float64 */
 int apzh_set_prior_mode(apzh_pool *p, int prior_is_f32);
-/* batched: visits[i][H*W] dense (0 where no child), n_children[i]; for MOVE_READY games */
+/* batched: visits[i][H*W] dense (-1 where the root has no child for that cell),
+ * n_children[i]; for MOVE_READY games */
 int apzh_root_visits_dense(apzh_pool *p, const int32_t *games, int n, int32_t *visits,
                            int32_t *n_children);
 /* MCTS.update_with_move: re-root at child `move`, or fresh root if absent / -1 */
