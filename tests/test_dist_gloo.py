@@ -1,0 +1,55 @@
+"""N > 1 path on CPU: 2 gloo ranks shard the games and all-gather the finished tuples."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+
+from alphapig_amd import dist
+from alphapig_amd.selfplay import SelfPlayEngine
+from fakenet import fake_policy_value_batch
+
+
+def test_shard_indices():
+    assert dist.shard_indices(10, 0, 4) == [0, 4, 8]
+    assert dist.shard_indices(10, 3, 4) == [3, 7]
+    assert sorted(sum((dist.shard_indices(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def test_single_process_passthrough():
+    c = np.zeros((3, 80), np.uint8)
+    p = np.ones((3, 64), np.float32)
+    z = np.array([1, -1, 0], np.float32)
+    g = dist.all_gather_tuples(c, p, z)
+    assert g[0].shape == (3, 80) and g[1].shape == (3, 64) and list(g[2]) == [1, -1, 0]
+    assert dist.all_reduce_max(3.5) == 3.5 and dist.all_reduce_sum(2.0) == 2.0
+
+
+def test_two_rank_gloo_allgather(tmp_path):
+    here = os.path.dirname(os.path.abspath(__file__))
+    total = 5
+    port = 29500 + random.randint(0, 2000)
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, "_dist_worker.py"),
+           str(tmp_path), str(total)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert list(r0["idx"]) == [0, 2, 4] and list(r1["idx"]) == [1, 3]
+    for k in ("codes", "pis", "zs"):
+        want = np.concatenate([r0[k], r1[k]])
+        for rank in (0, 1):
+            got = np.load(tmp_path / ("gathered%d.npz" % rank))[k]
+            np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(np.load(tmp_path / "gathered_empty1.npz")[k], r1[k])
+    # sharded games are the same games a single engine plays (seed = base + global index)
+    eng = SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=3, n_playout=16, temp=1.0, base_seed=555,
+                         n_threads=1, pipeline=1, forced_opening=False)
+    eps = eng.play_games(total)
+    lens = {int(i): int(l) for r in (r0, r1) for i, l in zip(r["idx"], r["lens"])}
+    assert [len(e.moves) for e in eps] == [lens[i] for i in range(total)]
+    np.testing.assert_array_equal(np.concatenate([eps[i].codes for i in (0, 2, 4)]), r0["codes"])
+    eng.close()
