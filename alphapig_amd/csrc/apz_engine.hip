@@ -14,6 +14,7 @@
 #include "alphapig_hip.h"
 #include "conv3x3_mfma.h"
 #include "heads.h"
+#include "trunk15_ring.h"
 
 namespace {
 
@@ -74,6 +75,8 @@ struct apz_engine {
     float *h_planes = nullptr, *h_probs = nullptr, *h_values = nullptr;
     unsigned char* h_codes = nullptr;
     int last_n = 0;
+    bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
+    int act_ps = 0, act_rs = 0;
     // profiling
     bool profiling = false;
     std::vector<Pending> pending;
@@ -207,15 +210,16 @@ void resolve_pending(apz_engine* e) {
     e->pending.clear();
 }
 
-template <int H, int W, int CT>
-int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+template <int H, int W, int CT, bool RESID>
+int launch_conv_r(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n,
+                  int out_ps, int out_rs) {
     using G = apz::ConvGeo<H, W>;
     // keep channel chunks a power-of-two-ish split of Cin: 256 ch at 15x15 -> 2 x 128
     int cchunk = L.cin_pad;
     while (cchunk > G::max_chunk()) cchunk = ((cchunk / 2) + 3) & ~3;
     const int lds = G::lds_bytes(cchunk);
     static int configured_lds = -1;
-    auto kern = apz::conv3x3_mfma_kernel<H, W, CT>;
+    auto kern = apz::conv3x3_mfma_kernel<H, W, CT, RESID>;
     if (lds > configured_lds) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_lds = lds;
@@ -224,13 +228,44 @@ int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const floa
     int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(lds, 1)));
     int grid = std::min(n, e->num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, resid, out, n, L.cin,
-                       L.cin_pad, cchunk, 1);
+                       L.cin_pad, cchunk, 1, out_ps, out_rs);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+template <int H, int W, int CT>
+int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    // the stem of the ring path hands its output to trunk15_ring.h in rows16 layout
+    const bool to16 = e->ring && &L == &e->convs[0];
+    const int ps = to16 ? e->act_ps : H * W, rs = to16 ? e->act_rs : W;
+    if (resid) return launch_conv_r<H, W, CT, true>(e, L, in, resid, out, n, ps, rs);
+    return launch_conv_r<H, W, CT, false>(e, L, in, resid, out, n, ps, rs);
+}
+
+int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Trunk15;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T::LDS_BYTES));
+        configured = true;
+    }
+    const int grid = std::min(n, e->num_cu);   // one persistent workgroup per CU (LDS-bound)
+    if (resid)
+        hipLaunchKernelGGL(apz::trunk15_ring_kernel<true>, dim3(grid), dim3(256), T::LDS_BYTES, e->stream, in, L.wpk,
+                           L.bias, resid, out, n);
+    else
+        hipLaunchKernelGGL(apz::trunk15_ring_kernel<false>, dim3(grid), dim3(256), T::LDS_BYTES, e->stream, in, L.wpk,
+                           L.bias, resid, out, n);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
 
 int launch_conv(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
     const int H = e->cfg.height, W = e->cfg.width, ct = L.cout / 64;
+    if (e->ring && &L != &e->convs[0]) return launch_trunk_ring(e, L, in, resid, out, n);
     if (H == 15 && W == 15) {
         if (ct == 2) return launch_conv_t<15, 15, 2>(e, L, in, resid, out, n);
         if (ct == 1) return launch_conv_t<15, 15, 1>(e, L, in, resid, out, n);
@@ -289,7 +324,8 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
     {
         Timed tm(e, APZ_K_HEAD_CONV);
         hipLaunchKernelGGL(apz::head_conv1x1_kernel, dim3(std::min(n, e->num_cu * 8)), dim3(256), 0, e->stream, trunk,
-                           e->w6, e->b6, e->featp, e->featv, n, e->clast, hw);
+                           e->w6, e->b6, e->featp, e->featv, n, e->clast, hw, e->cfg.width,
+                           e->ring ? e->act_ps : hw, e->ring ? e->act_rs : e->cfg.width);
         HIP_TRY(hipGetLastError());
     }
     {
@@ -414,10 +450,17 @@ apz_engine* apz_create(const apz_config* cfg) {
     e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", err);
+    e->ring = cfg->net_kind == APZ_NET_RESNET && cfg->height == 15 && cfg->width == 15 && cfg->n_filter == 128;
+    e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
+    e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
     const size_t B = cfg->max_batch, hw = e->hw;
-    const size_t act_bytes = B * e->cmax * hw * sizeof(float);
+    const size_t act_bytes = B * e->cmax * (size_t)e->act_ps * sizeof(float);
     for (int i = 0; i < 3; i++)
+    {
         if ((err = hipMalloc((void**)&e->act[i], act_bytes)) != hipSuccess) return bail("hipMalloc(act)", err);
+        // rows16 pad columns must read as zero; they are never written with anything else
+        if ((err = hipMemset(e->act[i], 0, act_bytes)) != hipSuccess) return bail("hipMemset(act)", err);
+    }
     if ((err = hipMalloc((void**)&e->planes, B * 9 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->featp, B * 4 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->featv, B * 2 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
@@ -724,8 +767,18 @@ int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
     int rc = run_trunk(e, e->planes, e->last_n, layer, &buf);
     e->profiling = was;
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(host_out, buf, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (!e->ring) {
+        HIP_TRY(hipMemcpyAsync(host_out, buf, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return APZ_OK;
+    }
+    const int C = e->convs[layer].cout, H = e->cfg.height, W = e->cfg.width;
+    std::vector<float> tmp((size_t)e->last_n * C * e->act_ps);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), buf, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    for (size_t pc = 0; pc < (size_t)e->last_n * C; pc++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) host_out[(pc * H + y) * W + x] = tmp[pc * e->act_ps + y * e->act_rs + x];
     return APZ_OK;
 }
 

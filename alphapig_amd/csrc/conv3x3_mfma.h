@@ -49,13 +49,14 @@ struct ConvGeo {
 };
 
 // wpk layout: [Cout/16][Cin_pad/4][9][64]  (see pack_conv3x3 in apz_engine.hip)
-template <int H, int W, int CT>
+template <int H, int W, int CT, bool RESID>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restrict__ in,
                                                            const float* __restrict__ wpk,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ resid,
                                                            float* __restrict__ out, int n, int cin,
-                                                           int cin_pad, int cchunk, int relu) {
+                                                           int cin_pad, int cchunk, int relu,
+                                                           int out_ps, int out_rs) {
     using G = ConvGeo<H, W>;
     constexpr int HW = H * W;
     extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -157,9 +158,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
             }
         }
 
-        // ---- epilogue: + folded bias (+ residual), ReLU, dense NCHW store
-        float* dst = out + (size_t)b * cout * HW;
-        const float* rsd = resid ? resid + (size_t)b * cout * HW : nullptr;
+        // ---- epilogue: + folded bias (+ residual), ReLU; output plane stride out_ps, row stride
+        //      out_rs (dense NCHW: H*W / W; rows16 hand-off to trunk15_ring.h: 240 / 16)
+        float* dst = out + (size_t)b * cout * out_ps;
+        const float* rsd = RESID ? resid + (size_t)b * cout * out_ps : nullptr;
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             const int co0 = (wave * CT + ct) * 16 + q * 4;
@@ -170,13 +172,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
             for (int t = 0; t < G::NT; t++) {
                 const int y = t * G::RPT + prow;
                 if (px < W && y < H) {
-                    const int p = y * W + px;
+                    const int p = y * out_rs + px;
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++) {
                         float v = acc[ct][t][rr] + bv[rr];
-                        if (rsd) v += rsd[(co0 + rr) * HW + p];
+                        if (RESID) v += rsd[(co0 + rr) * out_ps + p];
                         if (relu) v = fmaxf(v, 0.f);
-                        dst[(co0 + rr) * HW + p] = v;
+                        dst[(co0 + rr) * out_ps + p] = v;
                     }
                 }
             }

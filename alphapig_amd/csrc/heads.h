@@ -19,13 +19,16 @@ namespace apz {
 // w6 [6][C] (rows 0-3 policy, 4-5 value, BN folded), b6 [6]
 __global__ __launch_bounds__(256) void head_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w6,
                                                            const float* __restrict__ b6, float* __restrict__ featp,
-                                                           float* __restrict__ featv, int n, int C, int HW) {
+                                                           float* __restrict__ featv, int n, int C, int HW, int W, int in_ps,
+                                                           int in_rs) {
+    // input plane stride in_ps / row stride in_rs: dense NCHW (HW / W) or rows16 (240 / 16)
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
-        const float* xb = x + (size_t)b * C * HW;
+        const float* xb = x + (size_t)b * C * in_ps;
         for (int p = threadIdx.x; p < HW; p += blockDim.x) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
+            const int pin = (p / W) * in_rs + (p % W);
             for (int c = 0; c < C; c++) {
-                const float v = xb[c * HW + p];
+                const float v = xb[c * in_ps + pin];
                 a0 = fmaf(w6[0 * C + c], v, a0);
                 a1 = fmaf(w6[1 * C + c], v, a1);
                 a2 = fmaf(w6[2 * C + c], v, a2);

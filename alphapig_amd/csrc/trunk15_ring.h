@@ -1,0 +1,172 @@
+// Trunk 3x3 convolution (128 -> 128 channels, 15x15 board) + folded BN + (residual) + ReLU:
+// the kernel ~97 % of a leaf evaluation is spent in.  gfx950 only.
+//
+// Same im2col-free fp32-MFMA direct convolution as conv3x3_mfma.h, restructured so that the
+// matrix pipe never waits for staging:
+//
+//  * activations between trunk layers live in HBM as [n][128][15][16] floats ("rows16": every
+//    board row padded to 16 floats, the 16th always 0).  A plane is 960 B, rows are 64-B
+//    aligned, so the epilogue moves 16 B per lane and staging is a linear copy.
+//  * LDS holds a RING of four 32-channel chunks (4 x 34 KB).  A chunk is filled by LDS-DMA
+//    (global_load_lds_dwordx4, no VGPRs): one 960-B plane per wave-instruction, each wave
+//    issues ONE plane per ci4 iteration (8 iterations x 4 waves = the 32 planes of the chunk
+//    three chunks ahead), i.e. ~4 us before the next counted wait -- the DMA is invisible.
+//    In LDS the planes are 272 floats apart (== 16 mod 32: the four ci lanes-groups of a
+//    ds_read_b32 fall on disjoint bank halves) and the 32 floats between two planes stay zero:
+//    they are the bottom halo row of one plane and the top halo row of the next; column 15
+//    of every row is the right halo of that row and the left halo of the next.
+//  * MFMA operands swapped w.r.t. conv3x3_mfma.h: D[16 px][16 co] += A[16 px][4 ci] * B[4 ci][16 co],
+//    so lane l holds 4 consecutive pixels (x = 4*(l>>4) .. +3) of channel co = l&15:
+//    one aligned global_store_dwordx4 (and one dwordx4 residual load) per accumulator tile.
+//  * persistent workgroups: the chunk stream runs across board boundaries, so the next board's
+//    first chunks land while the current board's epilogue stores drain.
+//
+// One barrier per chunk (2160 MFMAs per wave between barriers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv3x3_mfma.h"
+
+namespace apz {
+
+struct Trunk15 {
+    static constexpr int C = 128, H = 15, W = 15;
+    static constexpr int GROW = 16;              // global / LDS row stride (floats)
+    static constexpr int GPLANE = H * GROW;      // 240 floats = 960 B per plane in HBM
+    static constexpr int LPS = 272;              // LDS plane stride, == 16 (mod 32)
+    static constexpr int CH = 32;                // channels per ring slot
+    static constexpr int NSLOT = 4;
+    static constexpr int SLOT = CH * LPS;        // floats per slot
+    static constexpr int FRONT = 32;             // zero floats in front of slot 0 (row -1 of plane 0)
+    static constexpr int LDS_FLOATS = FRONT + NSLOT * SLOT + 32;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "ring must fit the 160 KiB LDS");
+};
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// in / resid / out: [n][128][15][16] rows16 layout; wpk: [8][32][9][64] (cot, ci4, tap, lane)
+template <bool RESID>
+__global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restrict__ in,
+                                                           const float* __restrict__ wpk,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ resid,
+                                                           float* __restrict__ out, int n) {
+    using T = Trunk15;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ring = lds + T::FRONT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, j = lane & 15;
+
+    for (int i = tid * 4; i < T::LDS_FLOATS; i += 256 * 4) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int nb = (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // boards of this workgroup
+    const int total_chunks = nb * 4;
+
+    // DMA plane number `pl` (0..7) of this wave for global chunk g: plane p = 4*pl + wave of the chunk
+    auto issue_plane = [&](int g, int pl) {
+        if (g < total_chunks) {
+            const int board = (int)blockIdx.x + (g >> 2) * (int)gridDim.x;
+            const int p = pl * 4 + wave;
+            const int c = (g & 3) * T::CH + p;
+            const float* src = in + ((size_t)board * T::C + c) * T::GPLANE + lane * 4;
+            float* dst = ring + (g & 3) * T::SLOT + p * T::LPS;
+            if (lane < 60) glds16(src, dst);
+        }
+    };
+
+    for (int g = 0; g < 3; g++)
+#pragma unroll
+        for (int pl = 0; pl < 8; pl++) issue_plane(g, pl);
+    __syncthreads();   // emits vmcnt(0): chunks 0..2 of the first board have landed for every wave
+
+    // this wave's two 16-channel tiles
+    const float* wbase = wpk + ((size_t)(wave * 2) * 32 * 9) * 64 + lane;
+    float a_cur[2][9], a_nxt[2][9];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = wbase[((size_t)ct * 32 * 9 + tap) * 64];
+
+    const int lane_off = q * T::LPS + j - 17;   // (row f-1, col j+kx-1) = f*16 + kx + (j - 17)
+
+    for (int bi = 0; bi < nb; bi++) {
+        const int board = (int)blockIdx.x + bi * (int)gridDim.x;
+        f32x4 acc[2][15];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int t = 0; t < 15; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int chunk = 0; chunk < 4; chunk++) {
+            const int g = bi * 4 + chunk;
+            const float* sptr = ring + (g & 3) * T::SLOT + lane_off;
+            for (int c4l = 0; c4l < 8; c4l++) {
+                const float* bptr = sptr + c4l * 4 * T::LPS;
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    float r[17];
+#pragma unroll
+                    for (int f = 0; f < 17; f++) r[f] = bptr[f * 16 + kx];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int t = 0; t < 15; t++)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ct++)
+                                acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[t + ky], a_cur[ct][ky * 3 + kx],
+                                                                                  acc[ct][t], 0, 0, 0);
+                    if (kx == 0) {
+                        // Issue this iteration's DMA plane and the next weights AFTER the first
+                        // third of the MFMAs: hipcc waits vmcnt(0) at the first use of an ordinary
+                        // load while an LDS-DMA is in flight, so that wait must find loads that
+                        // are two thirds of an iteration (~5.7k cycles) old, not fresh ones.
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_plane(g + 3, c4l);                       // lands ~3 chunks before it is read
+                        const int c4n = (chunk * 8 + c4l + 1) & 31;    // wraps to the next board's first step
+#pragma unroll
+                        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                            for (int tap = 0; tap < 9; tap++)
+                                a_nxt[ct][tap] = wbase[(((size_t)ct * 32 + c4n) * 9 + tap) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                    for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = a_nxt[ct][tap];
+            }
+            __syncthreads();   // slot g&3 fully consumed by all waves; pending DMA drained (vmcnt(0))
+        }
+
+        // ---- epilogue: lane holds pixels x = 4q..4q+3 of row t for channel co
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            const int co = (wave * 2 + ct) * 16 + j;
+            const float bv = bias[co];
+            const size_t pbase = ((size_t)board * T::C + co) * T::GPLANE + q * 4;
+#pragma unroll
+            for (int t = 0; t < 15; t++) {
+                f32x4 v = acc[ct][t];
+                if (RESID) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(resid + pbase + t * 16);
+                    v += rv;
+                }
+                v[0] = fmaxf(v[0] + bv, 0.f);
+                v[1] = fmaxf(v[1] + bv, 0.f);
+                v[2] = fmaxf(v[2] + bv, 0.f);
+                v[3] = (q == 3) ? 0.f : fmaxf(v[3] + bv, 0.f);   // column 15 is the halo: keep it zero
+                *reinterpret_cast<f32x4*>(out + pbase + t * 16) = v;
+            }
+        }
+    }
+}
+
+}  // namespace apz

@@ -206,12 +206,18 @@ class SelfPlayEngine(object):
         self.stats["rounds"] += n_steps
         return leafs
 
-    def play_games(self, total_games, max_steps=None):
-        """Play `total_games` complete episodes -> list[Episode] ordered by game index."""
+    def play_games(self, total_games, max_steps=None, progress=None):
+        """Play `total_games` complete episodes -> list[Episode] ordered by game index.
+        progress: optional callable(engine) invoked about every 20 s (long GPU runs must keep
+        printing)."""
         steps = 0
+        last = time.perf_counter()
         while self.stats["games"] < total_games:
             n = self.run_steps(64, total_games)
             steps += 64
+            if progress is not None and time.perf_counter() - last > 20.0:
+                progress(self)
+                last = time.perf_counter()
             if n == 0 and not any(s.active for s in self.slots):
                 break
             if max_steps is not None and steps >= max_steps:

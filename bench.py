@@ -138,7 +138,11 @@ def main():
         dist.barrier()
         net.sync()
         t0 = time.perf_counter()
-        eps = eng.play_games(args.full_games)
+        def progress(e):
+            print("[full-games] %.0fs games %d/%d moves %d leaf-evals %d" % (
+                time.perf_counter() - t0, e.stats["games"], args.full_games, e.stats["moves"],
+                e.stats["leaf_evals"]), file=sys.stderr, flush=True)
+        eps = eng.play_games(args.full_games, progress=progress)
         net.sync()
         dist.barrier()
         dt = dist.all_reduce_max(time.perf_counter() - t0)
