@@ -263,9 +263,22 @@ int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const 
     return APZ_OK;
 }
 
+int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
+    const int grid = std::min(n, e->num_cu * 2);   // two resident workgroups per CU
+    if (L.cin_pad == 4)
+        hipLaunchKernelGGL(apz::stem15_kernel<1>, dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
+    else if (L.cin_pad == 12)
+        hipLaunchKernelGGL(apz::stem15_kernel<3>, dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
+    else
+        return fail(APZ_E_UNSUPPORTED, "stem15: C_in must be 4 or 9");
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int launch_conv(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
     const int H = e->cfg.height, W = e->cfg.width, ct = L.cout / 64;
     if (e->ring && &L != &e->convs[0]) return launch_trunk_ring(e, L, in, resid, out, n);
+    if (e->ring) return launch_stem15(e, L, in, out, n);
     if (H == 15 && W == 15) {
         if (ct == 2) return launch_conv_t<15, 15, 2>(e, L, in, resid, out, n);
         if (ct == 1) return launch_conv_t<15, 15, 1>(e, L, in, resid, out, n);

@@ -93,15 +93,31 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < TPW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* arow = sm + j * ldf + q;
-    for (int s = 0; s < KS; s++) {
+    // K loop, 8 k-steps per trip so that the 8 x TPW weight-fragment loads (L2) of a trip are in
+    // flight together instead of one dependent L2 round trip per MFMA (KS = H*W: 225 = 28*8 + 1)
+    int s = 0;
+    for (; s + 8 <= KS; s += 8) {
+        float a[8], bw[TPW][8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + u)];
+#pragma unroll
+        for (int i = 0; i < TPW; i++) {
+            const int nt = min(wave + 4 * i, ntile - 1);   // clamp: surplus tiles recompute the last one
+#pragma unroll
+            for (int u = 0; u < 8; u++) bw[i][u] = wfc_pk[((size_t)nt * KS + s + u) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[i][u], acc[i], 0, 0, 0);
+    }
+    for (; s < KS; s++) {
         const float a = arow[4 * s];
 #pragma unroll
         for (int i = 0; i < TPW; i++) {
-            const int nt = wave + 4 * i;
-            if (nt < ntile) {   // wave-uniform
-                const float bw = wfc_pk[((size_t)nt * KS + s) * 64 + lane];
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[i], 0, 0, 0);
-            }
+            const int nt = min(wave + 4 * i, ntile - 1);
+            const float bw = wfc_pk[((size_t)nt * KS + s) * 64 + lane];
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[i], 0, 0, 0);
         }
     }
     __syncthreads();            // features consumed; reuse LDS for the logits

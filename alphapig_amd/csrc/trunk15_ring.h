@@ -170,3 +170,97 @@ __global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restri
 }
 
 }  // namespace apz
+
+namespace apz {
+
+// Stem 3x3 convolution (C_in = 4 or 9 planes -> 128 channels, 15x15) + folded BN + ReLU.
+// Output-write bound at C_in = 4 (17.5 FLOP/B): the whole job is to keep ~1 GB of stores per
+// 8192 boards streaming while the (small) contraction runs.  Same MFMA tile mapping and rows16
+// output as trunk15_ring_kernel, but:
+//   * the 12 (or 4) input planes of a board are 13 KB in LDS, so TWO workgroups are resident per
+//     CU (launch bound 2 waves/SIMD): one computes while the other drains its 123 KB of stores;
+//   * the packed weights (55 KB for the whole layer) are loaded into registers ONCE per
+//     persistent workgroup: the board loop issues no weight loads at all;
+//   * input is the dense NCHW [n][C_in][15][15] planes buffer of the C ABI (the external
+//     contract), re-laid-out while staging.
+// wpk: [8][C4][9][64]; out: rows16 [n][128][15][16].
+template <int C4>
+__global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int n, int cin) {
+    using T = Trunk15;
+    constexpr int NPL = 4 * C4;
+    constexpr int LDSF = T::FRONT + NPL * T::LPS + 32;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    float* tile = lds + T::FRONT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, j = lane & 15;
+
+    for (int i = tid; i < LDSF; i += 256) lds[i] = 0.f;
+
+    float a[2][C4][9];
+    const float* wbase = wpk + ((size_t)(wave * 2) * C4 * 9) * 64 + lane;
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int c4 = 0; c4 < C4; c4++)
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) a[ct][c4][tap] = wbase[(((size_t)ct * C4 + c4) * 9 + tap) * 64];
+    float bv[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) bv[ct] = bias[(wave * 2 + ct) * 16 + j];
+
+    const int lane_off = q * T::LPS + j - 17;
+    const int total = cin * 225;
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        __syncthreads();
+        const float* src = in + (size_t)b * total;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int c = idx / 225, rem = idx - c * 225;
+            const int y = rem / 15, x = rem - y * 15;
+            tile[c * T::LPS + y * 16 + x] = src[idx];
+        }
+        __syncthreads();
+
+        f32x4 acc[2][15];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int t = 0; t < 15; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c4 = 0; c4 < C4; c4++) {
+            const float* bptr = tile + lane_off + c4 * 4 * T::LPS;
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                float r[17];
+#pragma unroll
+                for (int f = 0; f < 17; f++) r[f] = bptr[f * 16 + kx];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int t = 0; t < 15; t++)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ct++)
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[t + ky], a[ct][c4][ky * 3 + kx],
+                                                                              acc[ct][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            const int co = (wave * 2 + ct) * 16 + j;
+            float* dst = out + ((size_t)b * T::C + co) * T::GPLANE + q * 4;
+#pragma unroll
+            for (int t = 0; t < 15; t++) {
+                f32x4 v = acc[ct][t];
+                v[0] = fmaxf(v[0] + bv[ct], 0.f);
+                v[1] = fmaxf(v[1] + bv[ct], 0.f);
+                v[2] = fmaxf(v[2] + bv[ct], 0.f);
+                v[3] = (q == 3) ? 0.f : fmaxf(v[3] + bv[ct], 0.f);
+                *reinterpret_cast<f32x4*>(dst + t * 16) = v;
+            }
+        }
+    }
+}
+
+}  // namespace apz

@@ -1,0 +1,112 @@
+"""GPU end-to-end: the batched engine driving the HIP evaluator (BASELINE configs 2 and 3 in
+miniature).  Move parity is checked the way SURVEY.md section 7 prescribes: the evaluator outputs
+the GPU produced are recorded and replayed into the sequential CPU oracle, so both trees see the
+SAME numbers (batched-vs-batch-1 float drift cannot flip a PUCT near-tie), while the numbers
+themselves are checked against the float64 net oracle at 1e-4 / 2e-5 elsewhere."""
+import random
+
+import numpy as np
+import pytest
+
+from alphapig_amd import weights
+from alphapig_amd.selfplay import SelfPlayEngine
+from oracle import net_ref, selfplay_ref
+from oracle.board_ref import RefBoard
+from oracle.mcts_ref import RefMCTSPlayer
+
+pytestmark = pytest.mark.gpu
+
+
+class Recorder(object):
+    def __init__(self, net):
+        self.net, self.table = net, {}
+
+    def evaluate_codes(self, codes):
+        p, v = self.net.evaluate_codes(codes)
+        for c, pi, vi in zip(codes, p, v):
+            self.table[c.tobytes()] = (pi.copy(), np.float32(vi))
+        return p, v
+
+
+def codes_of(board, stride):
+    hw = board.width * board.height
+    c = np.zeros(stride, dtype=np.uint8)
+    n = len(board.move_list)
+    for k, (m, who) in enumerate(zip(board.move_list, board.mover_list)):
+        c[m] = (1 if who == board.current_player else 5) + min(n - 1 - k, 3)
+    c[hw] = 1 if n % 2 == 0 else 0
+    return c.tobytes()
+
+
+def replay_fn(table, stride):
+    def fn(board):
+        p, v = table[codes_of(board, stride)]
+        legal = board.availables
+        return zip(legal, p[legal]), np.array([v], dtype=np.float32)
+    return fn
+
+
+class Never(object):
+    def random(self):
+        return 1.0
+
+
+@pytest.mark.parametrize("cfg", ["simple8", "resnet15"])
+def test_engine_on_gpu_equals_sequential_oracle_on_recorded_outputs(cfg):
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    if cfg == "simple8":      # BASELINE config 2 shape: 8x8, 4-in-row, simple net
+        w, nrow, npl, G, total = 8, 4, 60, 16, 20
+        prm = weights.init_params("simple", 8, 8, 9, seed=1, style="bench")
+        net = PolicyValueNet(8, 8, batch_size=64, model_params=prm, net_kind="simple")
+        forced = False
+    else:                     # BASELINE config 3 shape: 15x15, 5-in-row, residual net
+        w, nrow, npl, G, total = 15, 5, 24, 12, 12
+        prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=2, style="bench")
+        net = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=prm)
+        forced = True
+    rec = Recorder(net)
+    eng = SelfPlayEngine(rec, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=31337, n_threads=4,
+                         pipeline=2, forced_opening=forced)
+    eps = eng.play_games(total)
+    assert len(eps) >= total and len(rec.table) > 0
+    stride = eng.pool.code_stride
+    fn = replay_fn(rec.table, stride)
+    for e in eps[:6]:
+        b = RefBoard(w, w, nrow)
+        pl = RefMCTSPlayer(fn, c_puct=5, n_playout=npl, is_selfplay=1, rng=np.random.RandomState(31337 + e.index))
+        pyr = random.Random(31337 + e.index) if forced else Never()
+        winner, data = selfplay_ref.start_self_play(b, pl, temp=1.0, pyrandom=pyr)
+        assert winner == e.winner
+        np.testing.assert_array_equal(np.array(b.move_list), e.moves)
+        np.testing.assert_allclose(np.stack([d[1] for d in data]), e.pis, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(np.array([d[2] for d in data]), e.zs)
+    # and the recorded numbers are the network's: spot-check against the float64 oracle
+    keys = list(rec.table.keys())[:32]
+    codes = np.stack([np.frombuffer(k, dtype=np.uint8) for k in keys])
+    planes = eng.pool.codes_to_planes(codes, 9)
+    kind = "simple" if cfg == "simple8" else "resnet"
+    o = net_ref.forward(prm, planes, kind, 2, np.float64)
+    np.testing.assert_allclose(np.stack([rec.table[k][0] for k in keys]), o[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.array([rec.table[k][1] for k in keys]), o[3][:, 0], rtol=0, atol=2e-5)
+    eng.close()
+    net.close()
+
+
+def test_full_size_properties_1024_games():
+    """BASELINE config 3 at full width (1024 concurrent games, 10 blocks, n_playout=400) for a few
+    rounds: size-independent properties -- one leaf per active game per round, priors are a
+    distribution, visit counts add up, Q in [-1, 1]."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=1024, n_blocks=10, n_filter=128, model_params=prm)
+    eng = SelfPlayEngine(net, 15, 15, 5, n_games=1024, n_playout=400, temp=1.0, base_seed=1, pipeline=2)
+    rounds = 12
+    n = eng.run_steps(rounds)
+    assert n == 1024 * rounds
+    for g in (0, 511, 1023):
+        root = eng.pool.node_children(g, 0)
+        assert root["n"] == rounds and int(root["visits"].sum()) == rounds - 1
+        assert len(root["acts"]) < 225 or abs(float(root["prior"].sum()) - 1.0) < 1e-4
+        assert np.all(np.abs(root["q"]) <= 1.0 + 1e-6)
+    eng.close()
+    net.close()
