@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -77,6 +78,7 @@ struct apz_engine {
     int last_n = 0;
     bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
     int act_ps = 0, act_rs = 0;
+    int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
     // profiling
     bool profiling = false;
     std::vector<Pending> pending;
@@ -242,25 +244,31 @@ int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const floa
     return launch_conv_r<H, W, CT, false>(e, L, in, resid, out, n, ps, rs);
 }
 
-int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+template <int NW>
+int launch_trunk_ring_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
     using T = apz::Trunk15;
     static bool configured = false;
     if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T::LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_ring_kernel<true, NW>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_ring_kernel<false, NW>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         configured = true;
     }
     const int grid = std::min(n, e->num_cu);   // one persistent workgroup per CU (LDS-bound)
     if (resid)
-        hipLaunchKernelGGL(apz::trunk15_ring_kernel<true>, dim3(grid), dim3(256), T::LDS_BYTES, e->stream, in, L.wpk,
-                           L.bias, resid, out, n);
+        hipLaunchKernelGGL((apz::trunk15_ring_kernel<true, NW>), dim3(grid), dim3(64 * NW), T::LDS_BYTES, e->stream, in,
+                           L.wpk, L.bias, resid, out, n);
     else
-        hipLaunchKernelGGL(apz::trunk15_ring_kernel<false>, dim3(grid), dim3(256), T::LDS_BYTES, e->stream, in, L.wpk,
-                           L.bias, resid, out, n);
+        hipLaunchKernelGGL((apz::trunk15_ring_kernel<false, NW>), dim3(grid), dim3(64 * NW), T::LDS_BYTES, e->stream, in,
+                           L.wpk, L.bias, resid, out, n);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
+}
+
+int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    if (e->trunk_waves == 8) return launch_trunk_ring_t<8>(e, L, in, resid, out, n);
+    return launch_trunk_ring_t<4>(e, L, in, resid, out, n);
 }
 
 int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
@@ -464,6 +472,7 @@ apz_engine* apz_create(const apz_config* cfg) {
     if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", err);
     e->ring = cfg->net_kind == APZ_NET_RESNET && cfg->height == 15 && cfg->width == 15 && cfg->n_filter == 128;
+    if (const char* tw = getenv("APZ_TRUNK_WAVES")) e->trunk_waves = (atoi(tw) == 8) ? 8 : 4;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
     const size_t B = cfg->max_batch, hw = e->hw;

@@ -49,13 +49,18 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
 }
 
 // in / resid / out: [n][128][15][16] rows16 layout; wpk: [8][32][9][64] (cot, ci4, tap, lane)
-template <bool RESID>
-__global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restrict__ in,
-                                                           const float* __restrict__ wpk,
-                                                           const float* __restrict__ bias,
-                                                           const float* __restrict__ resid,
-                                                           float* __restrict__ out, int n) {
+// NW = waves per workgroup: 4 (one per SIMD, 2 channel tiles each) or 8 (two per SIMD, one channel
+// tile each: the second wave's MFMAs fill the first one's wait slots at iteration boundaries).
+template <bool RESID, int NW>
+__global__ __launch_bounds__(64 * NW) void trunk15_ring_kernel(const float* __restrict__ in,
+                                                               const float* __restrict__ wpk,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ resid,
+                                                               float* __restrict__ out, int n) {
     using T = Trunk15;
+    constexpr int NT = 64 * NW;
+    constexpr int CT = 8 / NW;            // 16-channel tiles per wave
+    constexpr int PPW = T::CH / NW;       // DMA planes per wave per chunk (8 or 4)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ring = lds + T::FRONT;
 
@@ -63,17 +68,17 @@ __global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, j = lane & 15;
 
-    for (int i = tid * 4; i < T::LDS_FLOATS; i += 256 * 4) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid * 4; i < T::LDS_FLOATS; i += NT * 4) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     const int nb = (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // boards of this workgroup
     const int total_chunks = nb * 4;
 
-    // DMA plane number `pl` (0..7) of this wave for global chunk g: plane p = 4*pl + wave of the chunk
+    // DMA plane number `pl` (0..PPW-1) of this wave for global chunk g: plane p = NW*pl + wave
     auto issue_plane = [&](int g, int pl) {
         if (g < total_chunks) {
             const int board = (int)blockIdx.x + (g >> 2) * (int)gridDim.x;
-            const int p = pl * 4 + wave;
+            const int p = pl * NW + wave;
             const int c = (g & 3) * T::CH + p;
             const float* src = in + ((size_t)board * T::C + c) * T::GPLANE + lane * 4;
             float* dst = ring + (g & 3) * T::SLOT + p * T::LPS;
@@ -83,14 +88,13 @@ __global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restri
 
     for (int g = 0; g < 3; g++)
 #pragma unroll
-        for (int pl = 0; pl < 8; pl++) issue_plane(g, pl);
+        for (int pl = 0; pl < PPW; pl++) issue_plane(g, pl);
     __syncthreads();   // emits vmcnt(0): chunks 0..2 of the first board have landed for every wave
 
-    // this wave's two 16-channel tiles
-    const float* wbase = wpk + ((size_t)(wave * 2) * 32 * 9) * 64 + lane;
-    float a_cur[2][9], a_nxt[2][9];
+    const float* wbase = wpk + ((size_t)(wave * CT) * 32 * 9) * 64 + lane;
+    float a_cur[CT][9], a_nxt[CT][9];
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++)
+    for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = wbase[((size_t)ct * 32 * 9 + tap) * 64];
 
@@ -98,9 +102,10 @@ __global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restri
 
     for (int bi = 0; bi < nb; bi++) {
         const int board = (int)blockIdx.x + bi * (int)gridDim.x;
-        f32x4 acc[2][15];
+        f32x4 acc[CT][15];
+        f32x4 res[CT][15];               // residual, prefetched during the last chunk
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++)
+        for (int ct = 0; ct < CT; ct++)
 #pragma unroll
             for (int t = 0; t < 15; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restri
 #pragma unroll
                         for (int t = 0; t < 15; t++)
 #pragma unroll
-                            for (int ct = 0; ct < 2; ct++)
+                            for (int ct = 0; ct < CT; ct++)
                                 acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[t + ky], a_cur[ct][ky * 3 + kx],
                                                                                   acc[ct][t], 0, 0, 0);
                     if (kx == 0) {
@@ -128,18 +133,37 @@ __global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restri
                         // load while an LDS-DMA is in flight, so that wait must find loads that
                         // are two thirds of an iteration (~5.7k cycles) old, not fresh ones.
                         __builtin_amdgcn_sched_barrier(0);
-                        issue_plane(g + 3, c4l);                       // lands ~3 chunks before it is read
-                        const int c4n = (chunk * 8 + c4l + 1) & 31;    // wraps to the next board's first step
+                        if (NW == 4 || c4l < PPW) issue_plane(g + 3, c4l);   // lands ~3 chunks before it is read
+                        const int c4n = (chunk * 8 + c4l + 1) & 31;          // wraps to the next board's first step
 #pragma unroll
-                        for (int ct = 0; ct < 2; ct++)
+                        for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                             for (int tap = 0; tap < 9; tap++)
                                 a_nxt[ct][tap] = wbase[(((size_t)ct * 32 + c4n) * 9 + tap) * 64];
+                        if (RESID && chunk == 3) {
+                            // residual tiles of this board, a few per iteration, a chunk ahead of the epilogue
+#pragma unroll
+                            for (int ct = 0; ct < CT; ct++) {
+                                const size_t pb = ((size_t)board * T::C + (wave * CT + ct) * 16 + j) * T::GPLANE + q * 4;
+#define APZ_RES_LOAD(T0) res[ct][T0] = *reinterpret_cast<const f32x4*>(resid + pb + (T0) * 16)
+                                switch (c4l) {   // wave-uniform; static register indices in every arm
+                                    case 0: APZ_RES_LOAD(0); APZ_RES_LOAD(1); break;
+                                    case 1: APZ_RES_LOAD(2); APZ_RES_LOAD(3); break;
+                                    case 2: APZ_RES_LOAD(4); APZ_RES_LOAD(5); break;
+                                    case 3: APZ_RES_LOAD(6); APZ_RES_LOAD(7); break;
+                                    case 4: APZ_RES_LOAD(8); APZ_RES_LOAD(9); break;
+                                    case 5: APZ_RES_LOAD(10); APZ_RES_LOAD(11); break;
+                                    case 6: APZ_RES_LOAD(12); APZ_RES_LOAD(13); break;
+                                    default: APZ_RES_LOAD(14); break;
+                                }
+#undef APZ_RES_LOAD
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
-                for (int ct = 0; ct < 2; ct++)
+                for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                     for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = a_nxt[ct][tap];
             }
@@ -148,17 +172,14 @@ __global__ __launch_bounds__(256) void trunk15_ring_kernel(const float* __restri
 
         // ---- epilogue: lane holds pixels x = 4q..4q+3 of row t for channel co
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) {
-            const int co = (wave * 2 + ct) * 16 + j;
+        for (int ct = 0; ct < CT; ct++) {
+            const int co = (wave * CT + ct) * 16 + j;
             const float bv = bias[co];
             const size_t pbase = ((size_t)board * T::C + co) * T::GPLANE + q * 4;
 #pragma unroll
             for (int t = 0; t < 15; t++) {
                 f32x4 v = acc[ct][t];
-                if (RESID) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(resid + pbase + t * 16);
-                    v += rv;
-                }
+                if (RESID) v += res[ct][t];
                 v[0] = fmaxf(v[0] + bv, 0.f);
                 v[1] = fmaxf(v[1] + bv, 0.f);
                 v[2] = fmaxf(v[2] + bv, 0.f);
