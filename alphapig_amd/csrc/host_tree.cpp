@@ -411,7 +411,7 @@ apzh_pool *apzh_create(const apzh_config *cfg) {
     p->hw = cfg->width * cfg->height;
     int nt = cfg->n_threads;
 #ifdef _OPENMP
-    if (nt <= 0) nt = omp_get_max_threads();
+    if (nt <= 0) nt = std::min(omp_get_max_threads(), 16);   // a 1-GPU box grants 16 cores
 #else
     nt = 1;
 #endif

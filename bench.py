@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--full-games", type=int, default=0, help="play this many COMPLETE games per GPU "
                     "instead of timing --steps (measures games/s and mean plies directly; minutes)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
+    ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
     args = ap.parse_args()
 
     rank, world, local = dist.init()
@@ -122,8 +123,13 @@ def main():
     from alphapig_amd.policy_value_net import PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
 
-    ncpu = os.cpu_count() or 1
-    threads = max(1, ncpu // max(world, 1))
+    # host threads for the tree pool: this process's CPU share (a 1-GPU box grants 16 cores; the
+    # host may show many more), split evenly between the ranks of a node
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(world, 1)))
     G = args.games
     prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
     net = PolicyValueNet(W, H, batch_size=G, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, device=local)
@@ -134,6 +140,8 @@ def main():
         return eng.stats["leaf_evals"] + eng.terminal_playouts()
 
     mean_plies, plies_src = load_mean_plies()
+    if args.mean_plies:
+        mean_plies, plies_src = args.mean_plies, "--mean-plies override (debug)"
     if args.full_games:
         dist.barrier()
         net.sync()
