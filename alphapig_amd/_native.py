@@ -95,7 +95,7 @@ HOST_SYMBOLS = ["apzh_last_error", "apzh_version", "apzh_create", "apzh_destroy"
 
 HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create", "apz_destroy",
                "apz_param_count", "apz_param_name", "apz_param_size", "apz_load_weights", "apz_forward",
-               "apz_forward_host", "apz_forward_codes_host", "apz_forward_codes_async", "apz_host_alloc",
+               "apz_forward_host", "apz_forward_codes_host", "apz_forward_codes_async", "apz_submit_codes", "apz_wait", "apz_host_alloc",
                "apz_host_free", "apz_encode_planes", "apz_augment8", "apz_sync", "apz_stream",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
                "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms"]
@@ -125,6 +125,8 @@ def hip():
         "apz_forward_host": (C.c_int, [vp, f32p, C.c_int, f32p, f32p]),
         "apz_forward_codes_host": (C.c_int, [vp, u8p, C.c_int, f32p, f32p]),
         "apz_forward_codes_async": (C.c_int, [vp, vp, C.c_int, vp, vp]),
+        "apz_submit_codes": (C.c_int, [vp, C.c_int, u8p, C.c_int]),
+        "apz_wait": (C.c_int, [vp, C.c_int, f32p, f32p]),
         "apz_host_alloc": (vp, [C.c_int64]),
         "apz_host_free": (None, [vp]),
         "apz_encode_planes": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

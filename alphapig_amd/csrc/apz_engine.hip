@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,17 @@ struct apz_engine {
     float *h_planes = nullptr, *h_probs = nullptr, *h_values = nullptr;
     unsigned char* h_codes = nullptr;
     int last_n = 0;
+    // stream-ordered submission slots (apz_submit_codes / apz_wait)
+    struct Slot {
+        unsigned char* h_codes = nullptr;
+        float *h_probs = nullptr, *h_values = nullptr;
+        float *d_probs = nullptr, *d_values = nullptr;
+        unsigned char* d_codes = nullptr;
+        hipEvent_t done = nullptr;
+        int n = 0;
+        bool busy = false;
+    } slots[APZ_MAX_SLOTS];
+    std::mutex submit_lock;
     bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
     int act_ps = 0, act_rs = 0;
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
@@ -420,6 +432,15 @@ void apz_destroy(apz_engine* e) {
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p};
     for (void* p : dev)
         if (p) hipFree(p);
+    for (auto& sl : e->slots) {
+        if (sl.h_codes) hipHostFree(sl.h_codes);
+        if (sl.h_probs) hipHostFree(sl.h_probs);
+        if (sl.h_values) hipHostFree(sl.h_values);
+        if (sl.d_probs) hipFree(sl.d_probs);
+        if (sl.d_values) hipFree(sl.d_values);
+        if (sl.d_codes) hipFree(sl.d_codes);
+        if (sl.done) hipEventDestroy(sl.done);
+    }
     void* host[] = {e->h_planes, e->h_probs, e->h_values, e->h_codes};
     for (void* p : host)
         if (p) hipHostFree(p);
@@ -648,6 +669,51 @@ int apz_forward_codes_host(apz_engine* e, const uint8_t* codes_host, int n, floa
     std::memcpy(probs_host, e->h_probs, (size_t)n * e->hw * sizeof(float));
     std::memcpy(values_host, e->h_values, n * sizeof(float));
     return APZ_OK;
+}
+
+int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) {
+    if (!e || !codes_host) return fail(APZ_E_ARG, "null argument");
+    if (slot < 0 || slot >= APZ_MAX_SLOTS) return fail(APZ_E_ARG, "slot out of range");
+    if (n < 1 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch must be in [1, max_batch]");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    apz_engine::Slot& sl = e->slots[slot];
+    if (sl.busy) return fail(APZ_E_STATE, "slot still in flight: call apz_wait first");
+    const size_t B = e->cfg.max_batch, hw = e->hw;
+    if (!sl.h_codes) {
+        HIP_TRY(hipHostMalloc((void**)&sl.h_codes, B * e->code_stride));
+        HIP_TRY(hipHostMalloc((void**)&sl.h_probs, B * hw * sizeof(float)));
+        HIP_TRY(hipHostMalloc((void**)&sl.h_values, B * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&sl.d_codes, B * e->code_stride));
+        HIP_TRY(hipMalloc((void**)&sl.d_probs, B * hw * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&sl.d_values, B * sizeof(float)));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    std::memcpy(sl.h_codes, codes_host, (size_t)n * e->code_stride);
+    HIP_TRY(hipMemcpyAsync(sl.d_codes, sl.h_codes, (size_t)n * e->code_stride, hipMemcpyHostToDevice, e->stream));
+    int rc = apz_encode_planes(e, sl.d_codes, n, e->cfg.c_in, e->planes);
+    if (rc) return rc;
+    rc = forward_dev(e, e->planes, n, sl.d_probs, sl.d_values, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(sl.h_probs, sl.d_probs, n * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(sl.h_values, sl.d_values, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipEventRecord(sl.done, e->stream));
+    sl.n = n;
+    sl.busy = true;
+    return APZ_OK;
+}
+
+int apz_wait(apz_engine* e, int slot, float* probs_host, float* values_host) {
+    if (!e || !probs_host || !values_host) return fail(APZ_E_ARG, "null argument");
+    if (slot < 0 || slot >= APZ_MAX_SLOTS) return fail(APZ_E_ARG, "slot out of range");
+    apz_engine::Slot& sl = e->slots[slot];
+    if (!sl.busy) return fail(APZ_E_STATE, "nothing submitted in this slot");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipEventSynchronize(sl.done));
+    std::memcpy(probs_host, sl.h_probs, (size_t)sl.n * e->hw * sizeof(float));
+    std::memcpy(values_host, sl.h_values, (size_t)sl.n * sizeof(float));
+    sl.busy = false;
+    return sl.n;
 }
 
 void* apz_host_alloc(int64_t bytes) {

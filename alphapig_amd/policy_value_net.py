@@ -156,6 +156,21 @@ class PolicyValueNet(object):
                                                    as_ptr(vals[s:s + k], C.c_float)))
         return probs, vals
 
+    # ---- stream-ordered slots: a second batch queued while the first runs (selfplay pipeline)
+    n_slots = 4
+
+    def evaluate_codes_slot(self, slot, codes):
+        """submit + wait on one slot; safe to call from one host thread per slot."""
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.code_stride)
+        n = c.shape[0]
+        if n > self.batchsize:
+            return self.evaluate_codes(c)
+        probs = np.empty((n, self.hw), dtype=np.float32)
+        vals = np.empty(n, dtype=np.float32)
+        self._ck(self.L.apz_submit_codes(self._h, int(slot), as_ptr(c, C.c_uint8), n))
+        self._ck(self.L.apz_wait(self._h, int(slot), as_ptr(probs, C.c_float), as_ptr(vals, C.c_float)))
+        return probs, vals
+
     # ---- reference API
     def policy_value(self, state_batch):
         """Batched forward (policy_value_net_mxnet.py:232-242): -> (acts [B,HW], vals [B,1])."""

@@ -56,6 +56,10 @@ class SelfPlayEngine(object):
         self.pool = TreePool(board_width, board_height, n_in_row, n_games=n_games, n_playout=n_playout,
                              c_puct=c_puct, prior_is_f32=True, n_threads=n_threads)
         self.evaluator = evaluator if hasattr(evaluator, "evaluate_codes") else PlanesEvaluator(evaluator, self.pool)
+        # An evaluator with stream-ordered slots (PolicyValueNet.evaluate_codes_slot) lets every
+        # pipeline group keep one batch queued on the SAME HIP stream: group B's kernels start the
+        # moment group A's last kernel ends, while kernels never run concurrently (clean timings).
+        self._slotted = hasattr(self.evaluator, "evaluate_codes_slot")
         self.G, self.hw = int(n_games), board_width * board_height
         self.n_playout, self.temp = int(n_playout), temp
         self.base_seed = int(base_seed)
@@ -70,7 +74,9 @@ class SelfPlayEngine(object):
         self.stats = collections.Counter()
         self.timers = collections.Counter()
         self._limit = None
-        self._exec = ThreadPoolExecutor(max_workers=1) if self.pipeline > 1 else None
+        n_workers = min(self.pipeline, getattr(self.evaluator, "n_slots", 1)) if self._slotted else 1
+        # one worker thread per slot; a worker serves its own groups in order
+        self._exec = ([ThreadPoolExecutor(max_workers=1) for _ in range(n_workers)] if self.pipeline > 1 else None)
 
     # ---- slot life cycle -------------------------------------------------------------------
     def _start_game(self, s):
@@ -159,9 +165,12 @@ class SelfPlayEngine(object):
             return np.zeros(0, np.int32), np.zeros((0, self.pool.code_stride), np.uint8)
         return np.concatenate(eval_ids), np.concatenate(eval_codes)
 
-    def _evaluate(self, codes):
+    def _evaluate(self, codes, slot=0):
         t0 = time.perf_counter()
-        out = self.evaluator.evaluate_codes(codes)
+        if self._slotted:
+            out = self.evaluator.evaluate_codes_slot(slot, codes)
+        else:
+            out = self.evaluator.evaluate_codes(codes)
         self.timers["eval_s"] += time.perf_counter() - t0
         return out
 
@@ -193,8 +202,11 @@ class SelfPlayEngine(object):
                 ids, codes = self._advance_group(grp)    # overlaps the other groups' evaluations
                 if len(ids):
                     busy = True
-                    inflight[gi] = (ids, self._exec.submit(self._evaluate, codes) if self._exec is not None
-                                    else self._evaluate(codes))
+                    if self._exec is not None:
+                        w = gi % len(self._exec)
+                        inflight[gi] = (ids, self._exec[w].submit(self._evaluate, codes, w))
+                    else:
+                        inflight[gi] = (ids, self._evaluate(codes))
             if not busy:
                 break
         for gi in sorted(inflight):
@@ -230,7 +242,8 @@ class SelfPlayEngine(object):
 
     def close(self):
         if self._exec is not None:
-            self._exec.shutdown(wait=True)
+            for ex in self._exec:
+                ex.shutdown(wait=True)
             self._exec = None
         self.pool.close()
 

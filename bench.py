@@ -132,7 +132,10 @@ def main():
     threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(world, 1)))
     G = args.games
     prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
-    net = PolicyValueNet(W, H, batch_size=G, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, device=local)
+    # one evaluator, one HIP stream; the pipeline groups queue their batches on it back to back
+    net = PolicyValueNet(W, H, batch_size=(G + args.pipeline - 1) // args.pipeline, n_blocks=N_BLOCKS,
+                         n_filter=N_FILTER, model_params=prm, device=local)
+    lanes = [net]
     eng = SelfPlayEngine(net, W, H, N_IN_ROW, n_games=G, n_playout=N_PLAYOUT, c_puct=5, temp=1.0, base_seed=20260000,
                          n_threads=threads, pipeline=args.pipeline, index_offset=rank, index_stride=world)
 
@@ -144,14 +147,12 @@ def main():
         mean_plies, plies_src = args.mean_plies, "--mean-plies override (debug)"
     if args.full_games:
         dist.barrier()
-        net.sync()
         t0 = time.perf_counter()
         def progress(e):
             print("[full-games] %.0fs games %d/%d moves %d leaf-evals %d" % (
                 time.perf_counter() - t0, e.stats["games"], args.full_games, e.stats["moves"],
                 e.stats["leaf_evals"]), file=sys.stderr, flush=True)
         eps = eng.play_games(args.full_games, progress=progress)
-        net.sync()
         dist.barrier()
         dt = dist.all_reduce_max(time.perf_counter() - t0)
         games = dist.all_reduce_sum(eng.stats["games"])
@@ -165,17 +166,20 @@ def main():
                    "winners": {str(k): int(sum(1 for e in eps if e.winner == k)) for k in (-1, 1, 2)}}
             print(json.dumps(res))
         eng.close()
-        net.close()
+        for ln in lanes:
+            ln.close()
         return
     if mean_plies is None:
         raise SystemExit("profiles/calibration_r01.json missing: run `python bench.py --full-games 1024` once")
 
     eng.run_steps(args.warmup)                       # W untimed warm-up steps
-    net.set_profiling(True)
+    for ln in lanes:
+        ln.set_profiling(True)
     p0, l0 = playouts_done(), eng.stats["leaf_evals"]
     host0, eval0 = eng.timers["host_s"], eng.timers["eval_s"]
     dist.barrier()
-    net.sync()
+    for ln in lanes:
+        ln.sync()                                    # == torch.cuda.synchronize() for the engine streams
     t0 = time.perf_counter()
     eng.run_steps(args.steps)                        # exactly K timed steps
     # the round's exchange: all-gather of the tuples of games that finished inside the window
@@ -190,17 +194,22 @@ def main():
             pis = np.zeros((0, H * W), np.float32)
             zs = np.zeros(0, np.float32)
         dist.all_gather_tuples(codes, pis, zs)
-    net.sync()
+    for ln in lanes:
+        ln.sync()
     dist.barrier()
     dt_local = time.perf_counter() - t0
     dt = dist.all_reduce_max(dt_local)
     playouts = dist.all_reduce_sum(playouts_done() - p0)
     leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0)
-    trunk_ms, trunk_cnt = net.kernel_time_ms("trunk")
-    net.set_profiling(False)
+    trunk_ms = trunk_cnt = 0
+    for ln in lanes:
+        ms_, cnt_ = ln.kernel_time_ms("trunk")
+        trunk_ms, trunk_cnt = trunk_ms + ms_, trunk_cnt + cnt_
+        ln.set_profiling(False)
     if rank != 0:
         eng.close()
-        net.close()
+        for ln in lanes:
+            ln.close()
         return
 
     games_per_s = playouts / N_PLAYOUT / mean_plies / dt
@@ -225,7 +234,8 @@ def main():
                      "flops_per_launch": trunk_flops(batch), "boards_per_launch": batch},
     }
     eng.close()
-    net.close()
+    for ln in lanes:
+        ln.close()
     if not args.no_extras and world == 1:
         line["roofline_stem"] = stem_roofline(local)
         line["cpu_baseline"] = cpu_baseline(mean_plies)

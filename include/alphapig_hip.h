@@ -89,6 +89,15 @@ int apz_forward_codes_host(apz_engine *e, const uint8_t *codes_host, int n, floa
  * must be pinned (apz_host_alloc) and stay valid until apz_sync() returns. */
 int apz_forward_codes_async(apz_engine *e, const uint8_t *codes_pinned, int n, float *probs_pinned,
                             float *values_pinned);
+/* Stream-ordered queue of up to APZ_MAX_SLOTS batches on the engine's ONE stream: submit copies
+ * the codes into the slot's pinned buffer and enqueues H2D, encode, forward, D2H and an event;
+ * wait blocks on that event and copies the slot's results out.  A second batch submitted while
+ * the first runs starts the moment the first one's last kernel ends (no host round trip in
+ * between).  submit calls are serialised by an internal lock; different slots may be submitted
+ * and waited from different host threads. */
+#define APZ_MAX_SLOTS 4
+int apz_submit_codes(apz_engine *e, int slot, const uint8_t *codes_host, int n);
+int apz_wait(apz_engine *e, int slot, float *probs_host, float *values_host);
 void *apz_host_alloc(int64_t bytes);   /* pinned host memory */
 void apz_host_free(void *p);
 

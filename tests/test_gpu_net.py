@@ -226,3 +226,30 @@ def test_augment8_matches_reference_tables(resnet3, golden_dir):
         L.apz_device_free(h, x)
     np.testing.assert_array_equal(so.astype(np.int32), g["e%d_state_perm" % k])
     np.testing.assert_array_equal(po.astype(np.int32), g["e%d_pi_perm" % k])
+
+
+def test_stream_ordered_slots(resnet3):
+    """Two batches queued back to back on the one stream give the same numbers as separate calls,
+    from different host threads, and slot misuse is reported."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from alphapig_amd.policy_value_net import EvaluatorError
+    net, prm = resnet3
+    codes_a, _ = random_positions(33, 15, seed=41)
+    codes_b, _ = random_positions(64, 15, seed=42)
+    pa, va = net.evaluate_codes(codes_a)
+    pb, vb = net.evaluate_codes(codes_b)
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        for _ in range(5):
+            fa = ex.submit(net.evaluate_codes_slot, 0, codes_a)
+            fb = ex.submit(net.evaluate_codes_slot, 1, codes_b)
+            ra, rb = fa.result(), fb.result()
+            np.testing.assert_array_equal(ra[0], pa)
+            np.testing.assert_array_equal(ra[1], va)
+            np.testing.assert_array_equal(rb[0], pb)
+            np.testing.assert_array_equal(rb[1], vb)
+    with pytest.raises(EvaluatorError):
+        net._ck(net.L.apz_wait(net._h, 2, pa.ctypes.data_as(C.POINTER(C.c_float)),
+                               va.ctypes.data_as(C.POINTER(C.c_float))))
+    with pytest.raises(EvaluatorError):
+        net.evaluate_codes_slot(7, codes_a)
