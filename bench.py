@@ -227,7 +227,7 @@ def main():
         "leaf_evals_per_s": leafs / dt,
         "playouts_per_s": playouts / dt,
         "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
-        "roofline": {"kernel": "conv3x3_mfma_kernel<15,15,2> (trunk 128->128 3x3 + BN + residual + ReLU)",
+        "roofline": {"kernel": "trunk15_ring_kernel<RESID,4> (trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward)",
                      "bound": "mfma", "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                      "frac": (achieved_tf / FP32_MATRIX_PEAK_TF) if achieved_tf else None, "traffic": None,
                      "us_per_launch": trunk_avg_ms * 1e3, "launches": trunk_cnt,

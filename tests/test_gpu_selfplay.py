@@ -40,7 +40,13 @@ def codes_of(board, stride):
 
 def replay_fn(table, stride):
     def fn(board):
-        p, v = table[codes_of(board, stride)]
+        key = codes_of(board, stride)
+        if key not in table:
+            # the reference evaluates terminal leaves too and discards the result
+            # (mcts_alphaZero.py:124-136); the engine never sends them to the GPU
+            assert board.game_end()[0], "oracle visited a non-terminal position the engine never evaluated"
+            return zip(board.availables, np.zeros(len(board.availables), np.float32)), np.zeros(1, np.float32)
+        p, v = table[key]
         legal = board.availables
         return zip(legal, p[legal]), np.array([v], dtype=np.float32)
     return fn
