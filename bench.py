@@ -214,6 +214,15 @@ def main():
 
     games_per_s = playouts / N_PLAYOUT / mean_plies / dt
     batch = G // args.pipeline
+    # HBM traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
+    # (cannot be collected from inside the process), committed under profiles/
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01_trunk_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("boards_per_launch") == batch:
+            traffic = tj["traffic_bytes_per_launch"]["mean"]
     trunk_avg_ms = trunk_ms / max(trunk_cnt, 1)
     achieved_tf = trunk_flops(batch) / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
     line = {
@@ -229,7 +238,8 @@ def main():
         "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
         "roofline": {"kernel": "trunk15_ring_kernel<RESID,4> (trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward)",
                      "bound": "mfma", "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": (achieved_tf / FP32_MATRIX_PEAK_TF) if achieved_tf else None, "traffic": None,
+                     "frac": (achieved_tf / FP32_MATRIX_PEAK_TF) if achieved_tf else None, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_trunk_traffic.json)",
                      "us_per_launch": trunk_avg_ms * 1e3, "launches": trunk_cnt,
                      "flops_per_launch": trunk_flops(batch), "boards_per_launch": batch},
     }
