@@ -285,10 +285,10 @@ int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const 
 
 int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
     const int grid = std::min(n, e->num_cu * 2);   // two resident workgroups per CU
-    if (L.cin_pad == 4)
-        hipLaunchKernelGGL(apz::stem15_kernel<1>, dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
-    else if (L.cin_pad == 12)
-        hipLaunchKernelGGL(apz::stem15_kernel<3>, dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
+    if (L.cin == 4)
+        hipLaunchKernelGGL((apz::stem15_kernel<1, 4>), dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
+    else if (L.cin == 9)
+        hipLaunchKernelGGL((apz::stem15_kernel<3, 9>), dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
     else
         return fail(APZ_E_UNSUPPORTED, "stem15: C_in must be 4 or 9");
     HIP_TRY(hipGetLastError());

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64 * NW) void trunk15_ring_kernel(const float* __re
     constexpr int NT = 64 * NW;
     constexpr int CT = 8 / NW;            // 16-channel tiles per wave
     constexpr int PPW = T::CH / NW;       // DMA planes per wave per chunk (8 or 4)
+    constexpr int RES_CHUNK = 1;          // chunk during which the residual burst is issued
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ring = lds + T::FRONT;
 
@@ -109,59 +110,63 @@ __global__ __launch_bounds__(64 * NW) void trunk15_ring_kernel(const float* __re
 #pragma unroll
             for (int t = 0; t < 15; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // Software pipeline over the 3 kx phases of every ci4 step: the 17 row fragments of phase
+        // p+1 are read from LDS while the 90 MFMAs of phase p issue, so the matrix pipe never sits
+        // behind an exposed ds_read latency (one wave per SIMD: nobody else would cover it).
+        // The c4l loop is unrolled by two so the ping-pong fragment arrays keep static indices.
+#define APZ_LOAD_ROWS(dst, ptr, kx_)                                  \
+    _Pragma("unroll") for (int f = 0; f < 17; f++) dst[f] = (ptr)[f * 16 + (kx_)];
+#define APZ_MFMA_PHASE(rows, kx_)                                                                      \
+    _Pragma("unroll") for (int ky = 0; ky < 3; ky++) _Pragma("unroll") for (int t = 0; t < 15; t++)    \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ct++) acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32( \
+            rows[t + ky], a_cur[ct][ky * 3 + (kx_)], acc[ct][t], 0, 0, 0);
         for (int chunk = 0; chunk < 4; chunk++) {
             const int g = bi * 4 + chunk;
             const float* sptr = ring + (g & 3) * T::SLOT + lane_off;
+            // first fragments of the NEXT chunk (already landed: its slot was drained two barriers ago)
+            const float* snext = ring + ((g + 1) & 3) * T::SLOT + lane_off;
+            float rA[17], rB[17];
+            APZ_LOAD_ROWS(rA, sptr, 0)
             for (int c4l = 0; c4l < 8; c4l++) {
                 const float* bptr = sptr + c4l * 4 * T::LPS;
+                const float* bnext = (c4l < 7) ? bptr + 4 * T::LPS : snext;
+                // ---- phase kx = 0 (rows in rA), prefetch kx = 1 into rB
+                APZ_LOAD_ROWS(rB, bptr, 1)
+                APZ_MFMA_PHASE(rA, 0)
+                {
+                    // Issue this iteration's DMA plane and the next weights AFTER the first third of
+                    // the MFMAs: hipcc waits vmcnt(0) at the first use of an ordinary load while an
+                    // LDS-DMA is in flight, so that wait must find loads that are two thirds of an
+                    // iteration (~5.7k cycles) old, not fresh ones.
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (NW == 4 || c4l < PPW) issue_plane(g + 3, c4l);   // lands ~3 chunks before it is read
+                    const int c4n = (chunk * 8 + c4l + 1) & 31;          // wraps to the next board's first step
 #pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    float r[17];
+                    for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-                    for (int f = 0; f < 17; f++) r[f] = bptr[f * 16 + kx];
+                        for (int tap = 0; tap < 9; tap++)
+                            a_nxt[ct][tap] = wbase[(((size_t)ct * 32 + c4n) * 9 + tap) * 64];
+                    if (RESID && chunk == RES_CHUNK && c4l == 0) {
+                        // all residual tiles of this board in ONE burst, chunks ahead of the epilogue:
+                        // the compiler's per-iteration vmcnt(0) (LDS-DMA in flight) then stalls at most
+                        // once per board on them instead of a little at every iteration top
 #pragma unroll
-                    for (int ky = 0; ky < 3; ky++)
+                        for (int ct = 0; ct < CT; ct++) {
+                            const size_t pb = ((size_t)board * T::C + (wave * CT + ct) * 16 + j) * T::GPLANE + q * 4;
 #pragma unroll
-                        for (int t = 0; t < 15; t++)
-#pragma unroll
-                            for (int ct = 0; ct < CT; ct++)
-                                acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[t + ky], a_cur[ct][ky * 3 + kx],
-                                                                                  acc[ct][t], 0, 0, 0);
-                    if (kx == 0) {
-                        // Issue this iteration's DMA plane and the next weights AFTER the first
-                        // third of the MFMAs: hipcc waits vmcnt(0) at the first use of an ordinary
-                        // load while an LDS-DMA is in flight, so that wait must find loads that
-                        // are two thirds of an iteration (~5.7k cycles) old, not fresh ones.
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (NW == 4 || c4l < PPW) issue_plane(g + 3, c4l);   // lands ~3 chunks before it is read
-                        const int c4n = (chunk * 8 + c4l + 1) & 31;          // wraps to the next board's first step
-#pragma unroll
-                        for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-                            for (int tap = 0; tap < 9; tap++)
-                                a_nxt[ct][tap] = wbase[(((size_t)ct * 32 + c4n) * 9 + tap) * 64];
-                        if (RESID && chunk == 3) {
-                            // residual tiles of this board, a few per iteration, a chunk ahead of the epilogue
-#pragma unroll
-                            for (int ct = 0; ct < CT; ct++) {
-                                const size_t pb = ((size_t)board * T::C + (wave * CT + ct) * 16 + j) * T::GPLANE + q * 4;
-#define APZ_RES_LOAD(T0) res[ct][T0] = *reinterpret_cast<const f32x4*>(resid + pb + (T0) * 16)
-                                switch (c4l) {   // wave-uniform; static register indices in every arm
-                                    case 0: APZ_RES_LOAD(0); APZ_RES_LOAD(1); break;
-                                    case 1: APZ_RES_LOAD(2); APZ_RES_LOAD(3); break;
-                                    case 2: APZ_RES_LOAD(4); APZ_RES_LOAD(5); break;
-                                    case 3: APZ_RES_LOAD(6); APZ_RES_LOAD(7); break;
-                                    case 4: APZ_RES_LOAD(8); APZ_RES_LOAD(9); break;
-                                    case 5: APZ_RES_LOAD(10); APZ_RES_LOAD(11); break;
-                                    case 6: APZ_RES_LOAD(12); APZ_RES_LOAD(13); break;
-                                    default: APZ_RES_LOAD(14); break;
-                                }
-#undef APZ_RES_LOAD
-                            }
+                            for (int t = 0; t < 15; t++) res[ct][t] = *reinterpret_cast<const f32x4*>(resid + pb + t * 16);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                // ---- phase kx = 1 (rB), prefetch kx = 2 into rA
+                APZ_LOAD_ROWS(rA, bptr, 2)
+                APZ_MFMA_PHASE(rB, 1)
+                // ---- phase kx = 2 (rA), prefetch the next step's kx = 0 into rB, then rotate
+                APZ_LOAD_ROWS(rB, bnext, 0)
+                APZ_MFMA_PHASE(rA, 2)
+#pragma unroll
+                for (int f = 0; f < 17; f++) rA[f] = rB[f];
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -169,6 +174,8 @@ __global__ __launch_bounds__(64 * NW) void trunk15_ring_kernel(const float* __re
             }
             __syncthreads();   // slot g&3 fully consumed by all waves; pending DMA drained (vmcnt(0))
         }
+#undef APZ_LOAD_ROWS
+#undef APZ_MFMA_PHASE
 
         // ---- epilogue: lane holds pixels x = 4q..4q+3 of row t for channel co
 #pragma unroll
@@ -205,7 +212,7 @@ namespace apz {
 //   * input is the dense NCHW [n][C_in][15][15] planes buffer of the C ABI (the external
 //     contract), re-laid-out while staging.
 // wpk: [8][C4][9][64]; out: rows16 [n][128][15][16].
-template <int C4>
+template <int C4, int CIN>
 __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int n, int cin) {
@@ -234,15 +241,40 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
 
     const int lane_off = q * T::LPS + j - 17;
     const int total = cin * 225;
-    for (int b = blockIdx.x; b < n; b += gridDim.x) {
-        __syncthreads();
+    constexpr int NPF = (CIN * 225 + 255) / 256;   // input floats per thread per board (4 or 8)
+    constexpr bool PREFETCH = (C4 == 1);           // C_in = 9 has no registers to spare (256-VGPR cap)
+    // The stores of board b must drain WHILE board b+1 computes.  vmcnt retires in order, so
+    // the next board's planes are loaded into registers BEFORE this board's stores are issued
+    // (their wait then never covers a store), and the barriers protecting the LDS tile are raw
+    // s_barrier + lgkmcnt(0): __syncthreads() would add vmcnt(0) and stall on the store acks.
+    float pf[NPF];
+    auto prefetch = [&](int b) {
         const float* src = in + (size_t)b * total;
-        for (int idx = tid; idx < total; idx += 256) {
-            const int c = idx / 225, rem = idx - c * 225;
-            const int y = rem / 15, x = rem - y * 15;
-            tile[c * T::LPS + y * 16 + x] = src[idx];
+#pragma unroll
+        for (int u = 0; u < NPF; u++) {
+            const int idx = tid + u * 256;
+            pf[u] = (b < n && idx < total) ? src[idx] : 0.f;
         }
-        __syncthreads();
+    };
+    auto lds_barrier = [&]() {
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0) only
+        __builtin_amdgcn_s_barrier();
+    };
+    __syncthreads();                          // zero fill done
+    prefetch(blockIdx.x);
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        if (!PREFETCH && b != (int)blockIdx.x) prefetch(b);
+#pragma unroll
+        for (int u = 0; u < NPF; u++) {
+            const int idx = tid + u * 256;
+            if (idx < total) {
+                const int c = idx / 225, rem = idx - c * 225;
+                const int y = rem / 15, x = rem - y * 15;
+                tile[c * T::LPS + y * 16 + x] = pf[u];
+            }
+        }
+        lds_barrier();
+        if (PREFETCH) prefetch(b + gridDim.x);  // lands during the MFMAs below
 
         f32x4 acc[2][15];
 #pragma unroll
@@ -267,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
                                                                               acc[ct][t], 0, 0, 0);
             }
         }
+        lds_barrier();                        // every wave is done reading the tile
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
             const int co = (wave * 2 + ct) * 16 + j;
