@@ -17,6 +17,7 @@
 #include "conv3x3_mfma.h"
 #include "heads.h"
 #include "trunk15_ring.h"
+#include "sampler.h"
 
 namespace {
 
@@ -754,6 +755,33 @@ int apz_augment8(apz_engine* e, const void* planes_dev, const void* pi_dev, int 
                        0, e->stream, (const float*)planes_dev, (const float*)pi_dev, e->perm_s, e->perm_p,
                        (float*)planes_out_dev, (float*)pi_out_dev, n, c, e->hw);
     HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_sample_moves_host(apz_engine* e, const int32_t* visits_host, int g, float temp, float alpha, float eps,
+                          uint64_t seed, uint64_t step, float* pi_host, int32_t* moves_host) {
+    if (!e || !visits_host || !pi_host || !moves_host) return fail(APZ_E_ARG, "null argument");
+    if (g < 1 || e->hw > 256 || !(temp > 0.f) || !(alpha > 0.f) || eps < 0.f || eps > 1.f)
+        return fail(APZ_E_ARG, "bad sampler arguments");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t hw = e->hw, vb = (size_t)g * hw * sizeof(int32_t);
+    int32_t* d_vis = nullptr;
+    float* d_pi = nullptr;
+    int32_t* d_mv = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_vis, vb));
+    HIP_TRY(hipMalloc((void**)&d_pi, (size_t)g * hw * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&d_mv, (size_t)g * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(d_vis, visits_host, vb, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(apz::root_sample_kernel, dim3(g), dim3(64), 0, e->stream, d_vis, d_pi, d_mv, g, (int)hw,
+                       1.0f / temp, alpha, eps, (unsigned long long)seed, (unsigned long long)step);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pi_host, d_pi, (size_t)g * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(moves_host, d_mv, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    hipFree(d_vis);
+    hipFree(d_pi);
+    hipFree(d_mv);
     return APZ_OK;
 }
 

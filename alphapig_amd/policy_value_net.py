@@ -171,6 +171,18 @@ class PolicyValueNet(object):
         self._ck(self.L.apz_wait(self._h, int(slot), as_ptr(probs, C.c_float), as_ptr(vals, C.c_float)))
         return probs, vals
 
+    def sample_moves(self, visits, temp=1.0, alpha=0.3, eps=0.25, seed=0, step=0):
+        """GPU root sampling (opt-in perf mode): visits int32 [g, HW] with -1 for non-children ->
+        (pi float32 [g, HW], moves int32 [g])."""
+        v = np.ascontiguousarray(visits, dtype=np.int32).reshape(-1, self.hw)
+        g = v.shape[0]
+        pi = np.empty((g, self.hw), dtype=np.float32)
+        mv = np.empty(g, dtype=np.int32)
+        self._ck(self.L.apz_sample_moves_host(self._h, as_ptr(v, C.c_int32), g, float(temp), float(alpha),
+                                              float(eps), int(seed), int(step), as_ptr(pi, C.c_float),
+                                              as_ptr(mv, C.c_int32)))
+        return pi, mv
+
     # ---- reference API
     def policy_value(self, state_batch):
         """Batched forward (policy_value_net_mxnet.py:232-242): -> (acts [B,HW], vals [B,1])."""

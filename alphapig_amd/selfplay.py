@@ -52,7 +52,7 @@ class _Slot(object):
 class SelfPlayEngine(object):
     def __init__(self, evaluator, board_width=15, board_height=15, n_in_row=5, n_games=1024, n_playout=400,
                  c_puct=5, temp=1.0, base_seed=0, n_threads=0, pipeline=2, noise_alpha=0.3, noise_eps=0.25,
-                 forced_opening=True, index_offset=0, index_stride=1):
+                 forced_opening=True, index_offset=0, index_stride=1, sampler="host"):
         self.pool = TreePool(board_width, board_height, n_in_row, n_games=n_games, n_playout=n_playout,
                              c_puct=c_puct, prior_is_f32=True, n_threads=n_threads)
         self.evaluator = evaluator if hasattr(evaluator, "evaluate_codes") else PlanesEvaluator(evaluator, self.pool)
@@ -68,6 +68,12 @@ class SelfPlayEngine(object):
         self.pipeline = max(1, int(pipeline))
         # multi-GPU sharding: this engine owns global games offset, offset+stride, ... (dist.py)
         self.index_offset, self.index_stride = int(index_offset), int(index_stride)
+        # "host": the reference's NumPy legacy stream per game (bit-exact parity mode, default);
+        # "gpu": root_sample_kernel (statistical parity only), no per-game Python sampling
+        if sampler not in ("host", "gpu"):
+            raise ValueError("sampler must be 'host' or 'gpu'")
+        self.sampler = sampler
+        self._sample_step = 0
         self.slots = [_Slot() for _ in range(self.G)]
         self.next_index = 0
         self.finished = []
@@ -122,6 +128,19 @@ class SelfPlayEngine(object):
     # ---- one move of every MOVE_READY slot (mcts_alphaZero.py:151-157, :187-203) ------------
     def _play_ready(self, ready):
         visits, _ = self.pool.root_visits_dense(ready)
+        if self.sampler == "gpu":
+            self._sample_step += 1
+            pis, moves = self.evaluator.sample_moves(visits, temp=self.temp, alpha=self.noise_alpha,
+                                                     eps=self.noise_eps, seed=self.base_seed, step=self._sample_step)
+            for pi, move, s in zip(pis, moves, ready):
+                s = int(s)
+                self._record(s, pi.astype(np.float64))
+                ended, winner, _ = self.pool.play_move(s, int(move))
+                self.stats["moves"] += 1
+                if ended:
+                    self._finish_game(s, winner)
+                    self._start_game(s)
+            return
         for row, s in zip(visits, ready):
             s = int(s)
             slot = self.slots[s]

@@ -108,6 +108,13 @@ int apz_encode_planes(apz_engine *e, const void *codes_dev, int n, int n_planes,
 int apz_augment8(apz_engine *e, const void *planes_dev, const void *pi_dev, int n, int c,
                  void *planes_out_dev, void *pi_out_dev);
 
+/* Root move sampling on the GPU (opt-in; NOT bit-compatible with the reference's NumPy stream):
+ * visits_host [g][H*W] int32 with -1 where the root has no child; pi_host [g][H*W] gets
+ * softmax(log(visits+1e-10)/temp) (mcts_alphaZero.py:152-155), moves_host[g] a draw from
+ * (1-eps)*pi + eps*Dirichlet(alpha) (:198-201).  Deterministic in (seed, step, game index). */
+int apz_sample_moves_host(apz_engine *e, const int32_t *visits_host, int g, float temp, float alpha,
+                          float eps, uint64_t seed, uint64_t step, float *pi_host, int32_t *moves_host);
+
 int apz_sync(apz_engine *e);
 void *apz_stream(apz_engine *e);
 void *apz_device_alloc(apz_engine *e, int64_t bytes);
