@@ -284,16 +284,24 @@ int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const 
     return launch_trunk_ring_t<4>(e, L, in, resid, out, n);
 }
 
-int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
+template <int C4, int CIN>
+int launch_stem15_t(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
+    constexpr int lds = apz::stem15_lds_bytes<C4>();
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::stem15_kernel<C4, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
     const int grid = std::min(n, e->num_cu * 2);   // two resident workgroups per CU
-    if (L.cin == 4)
-        hipLaunchKernelGGL((apz::stem15_kernel<1, 4>), dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
-    else if (L.cin == 9)
-        hipLaunchKernelGGL((apz::stem15_kernel<3, 9>), dim3(grid), dim3(256), 0, e->stream, in, L.wpk, L.bias, out, n, L.cin);
-    else
-        return fail(APZ_E_UNSUPPORTED, "stem15: C_in must be 4 or 9");
+    hipLaunchKernelGGL((apz::stem15_kernel<C4, CIN>), dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, out, n, L.cin);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
+}
+
+int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
+    if (L.cin == 4) return launch_stem15_t<1, 4>(e, L, in, out, n);
+    if (L.cin == 9) return launch_stem15_t<3, 9>(e, L, in, out, n);
+    return fail(APZ_E_UNSUPPORTED, "stem15: C_in must be 4 or 9");
 }
 
 int launch_conv(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
     using T = Trunk15;
     constexpr int NPL = 4 * C4;
     constexpr int LDSF = T::FRONT + NPL * T::LPS + 32;
-    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    constexpr int OST = 244;                       // staged output row stride: 16 lanes x 16 B hit 64 distinct banks
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [LDSF tile][4 waves x 16 x OST staging]
     float* tile = lds + T::FRONT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,10 +301,12 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
             }
         }
         lds_barrier();                        // every wave is done reading the tile
+        // ---- epilogue through LDS: the accumulator layout gives 64-B pieces per (channel, row);
+        // written straight to HBM that pattern tops out at ~4.2 TB/s.  Each wave transposes its
+        // 16-channel tile in a private LDS staging area and streams whole 960-B planes instead.
+        float* st = lds + LDSF + wave * (16 * OST);
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
-            const int co = (wave * 2 + ct) * 16 + j;
-            float* dst = out + ((size_t)b * T::C + co) * T::GPLANE + q * 4;
 #pragma unroll
             for (int t = 0; t < 15; t++) {
                 f32x4 v = acc[ct][t];
@@ -311,10 +314,22 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
                 v[1] = fmaxf(v[1] + bv[ct], 0.f);
                 v[2] = fmaxf(v[2] + bv[ct], 0.f);
                 v[3] = (q == 3) ? 0.f : fmaxf(v[3] + bv[ct], 0.f);
-                *reinterpret_cast<f32x4*>(dst + t * 16) = v;
+                *reinterpret_cast<f32x4*>(st + j * OST + t * 16 + q * 4) = v;
+            }
+            float* dst = out + ((size_t)b * T::C + (wave * 2 + ct) * 16) * T::GPLANE + lane * 4;
+            if (lane < 60) {
+#pragma unroll
+                for (int c = 0; c < 16; c++)
+                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(st + c * OST + lane * 4),
+                                                reinterpret_cast<f32x4*>(dst + c * T::GPLANE));
             }
         }
     }
+}
+
+template <int C4>
+constexpr int stem15_lds_bytes() {
+    return (Trunk15::FRONT + 4 * C4 * Trunk15::LPS + 32 + 4 * 16 * 244) * (int)sizeof(float);
 }
 
 }  // namespace apz
