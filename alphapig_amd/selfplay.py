@@ -52,7 +52,7 @@ class _Slot(object):
 class SelfPlayEngine(object):
     def __init__(self, evaluator, board_width=15, board_height=15, n_in_row=5, n_games=1024, n_playout=400,
                  c_puct=5, temp=1.0, base_seed=0, n_threads=0, pipeline=2, noise_alpha=0.3, noise_eps=0.25,
-                 forced_opening=True, index_offset=0, index_stride=1, sampler="host"):
+                 forced_opening=True, index_offset=0, index_stride=1, sampler="host", temp_schedule=None):
         self.pool = TreePool(board_width, board_height, n_in_row, n_games=n_games, n_playout=n_playout,
                              c_puct=c_puct, prior_is_f32=True, n_threads=n_threads)
         self.evaluator = evaluator if hasattr(evaluator, "evaluate_codes") else PlanesEvaluator(evaluator, self.pool)
@@ -62,6 +62,9 @@ class SelfPlayEngine(object):
         self._slotted = hasattr(self.evaluator, "evaluate_codes_slot")
         self.G, self.hw = int(n_games), board_width * board_height
         self.n_playout, self.temp = int(n_playout), temp
+        # The reference plays every ply at one constant `temp`.  Optional extension
+        # (BASELINE config 5): temp_schedule = [(first_ply, temp), ...] ascending, or callable(ply).
+        self.temp_schedule = temp_schedule
         self.base_seed = int(base_seed)
         self.noise_alpha, self.noise_eps = noise_alpha, noise_eps
         self.forced_opening = forced_opening
@@ -125,13 +128,31 @@ class SelfPlayEngine(object):
         self.stats["games"] += 1
         self.stats["plies"] += len(movers)
 
+    def _temp_for(self, ply):
+        sch = self.temp_schedule
+        if sch is None:
+            return self.temp
+        if callable(sch):
+            return float(sch(ply))
+        t = self.temp
+        for first, val in sch:
+            if ply >= first:
+                t = val
+        return t
+
     # ---- one move of every MOVE_READY slot (mcts_alphaZero.py:151-157, :187-203) ------------
     def _play_ready(self, ready):
         visits, _ = self.pool.root_visits_dense(ready)
         if self.sampler == "gpu":
             self._sample_step += 1
-            pis, moves = self.evaluator.sample_moves(visits, temp=self.temp, alpha=self.noise_alpha,
-                                                     eps=self.noise_eps, seed=self.base_seed, step=self._sample_step)
+            temps = [self._temp_for(len(self.slots[int(s)].movers)) for s in ready]
+            pis = np.empty((len(ready), self.hw), dtype=np.float32)
+            moves = np.empty(len(ready), dtype=np.int32)
+            for t in sorted(set(temps)):            # one launch per distinct temperature
+                sel = np.array([i for i, ti in enumerate(temps) if ti == t])
+                pis[sel], moves[sel] = self.evaluator.sample_moves(
+                    visits[sel], temp=t, alpha=self.noise_alpha, eps=self.noise_eps,
+                    seed=self.base_seed + 7919 * int(sel[0]), step=self._sample_step)
             for pi, move, s in zip(pis, moves, ready):
                 s = int(s)
                 self._record(s, pi.astype(np.float64))
@@ -145,7 +166,7 @@ class SelfPlayEngine(object):
             s = int(s)
             slot = self.slots[s]
             acts = np.flatnonzero(row >= 0)
-            x = 1.0 / self.temp * np.log(row[acts].astype(np.int64) + 1e-10)
+            x = 1.0 / self._temp_for(len(slot.movers)) * np.log(row[acts].astype(np.int64) + 1e-10)
             probs = np.exp(x - np.max(x))
             probs /= np.sum(probs)
             pi = np.zeros(self.hw)

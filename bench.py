@@ -115,9 +115,12 @@ def main():
                     "instead of timing --steps (measures games/s and mean plies directly; minutes)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
+    ap.add_argument("--plumbing-test", action="store_true",
+                    help="CPU self-test of the multi-rank plumbing (gloo, stand-in evaluator from tests/fakenet.py, "
+                         "8 games per rank); the JSON line is marked invalid and is NOT a measurement")
     args = ap.parse_args()
 
-    rank, world, local = dist.init()
+    rank, world, local = dist.init(backend="gloo" if args.plumbing_test else None)
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     from alphapig_amd.policy_value_net import PolicyValueNet
@@ -131,13 +134,40 @@ def main():
         ncpu = os.cpu_count() or 1
     threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(world, 1)))
     G = args.games
-    prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
-    # one evaluator, one HIP stream; the pipeline groups queue their batches on it back to back
-    net = PolicyValueNet(W, H, batch_size=(G + args.pipeline - 1) // args.pipeline, n_blocks=N_BLOCKS,
-                         n_filter=N_FILTER, model_params=prm, device=local)
+    if args.plumbing_test:
+        class _StandIn(object):      # counts like the real evaluator; numbers come from tests/fakenet.py
+            def __init__(self):
+                sys.path.insert(0, os.path.join(REPO, "tests"))
+                from fakenet import fake_policy_value_batch
+                self.fn, self.pool = fake_policy_value_batch, None
+
+            def evaluate_codes(self, codes):
+                return self.fn(self.pool.codes_to_planes(codes, 9))
+
+            def sync(self):
+                pass
+
+            def set_profiling(self, on):
+                pass
+
+            def kernel_time_ms(self, k):
+                return 0.0, 0
+
+            def close(self):
+                pass
+        G = 8
+        net = _StandIn()
+    else:
+        prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
+        # one evaluator, one HIP stream; the pipeline groups queue their batches on it back to back
+        net = PolicyValueNet(W, H, batch_size=(G + args.pipeline - 1) // args.pipeline, n_blocks=N_BLOCKS,
+                             n_filter=N_FILTER, model_params=prm, device=local)
     lanes = [net]
     eng = SelfPlayEngine(net, W, H, N_IN_ROW, n_games=G, n_playout=N_PLAYOUT, c_puct=5, temp=1.0, base_seed=20260000,
                          n_threads=threads, pipeline=args.pipeline, index_offset=rank, index_stride=world)
+
+    if args.plumbing_test:
+        net.pool = eng.pool
 
     def playouts_done():
         return eng.stats["leaf_evals"] + eng.terminal_playouts()
@@ -246,7 +276,10 @@ def main():
     eng.close()
     for ln in lanes:
         ln.close()
-    if not args.no_extras and world == 1:
+    if args.plumbing_test:
+        line["valid"] = False
+        line["data"] = "plumbing-test (CPU stand-in evaluator, 8 games per rank): NOT a measurement"
+    if not args.no_extras and world == 1 and not args.plumbing_test:
         line["roofline_stem"] = stem_roofline(local)
         line["cpu_baseline"] = cpu_baseline(mean_plies)
     print(json.dumps(line))

@@ -53,3 +53,26 @@ def test_two_rank_gloo_allgather(tmp_path):
     assert [len(e.moves) for e in eps] == [lens[i] for i in range(total)]
     np.testing.assert_array_equal(np.concatenate([eps[i].codes for i in (0, 2, 4)]), r0["codes"])
     eng.close()
+
+
+def test_bench_multi_rank_plumbing(tmp_path):
+    """`torchrun ... bench.py --gpus 2` end to end on CPU ranks (gloo + stand-in evaluator):
+    argument handling, rank sharding, barriers, MAX/SUM reductions, the tuple all-gather and the
+    single JSON line from rank 0."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 31500 + random.randint(0, 2000)
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "6", "--warmup", "2", "--plumbing-test"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["valid"] is False and d["vs_baseline"] is None and d["unit"] == "games/s"
+    assert d["leaf_evals_per_s"] > 0 and d["value"] > 0
+    assert d["config"]["games_per_gpu"] == 8

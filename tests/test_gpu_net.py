@@ -253,3 +253,15 @@ def test_stream_ordered_slots(resnet3):
                                va.ctypes.data_as(C.POINTER(C.c_float))))
     with pytest.raises(EvaluatorError):
         net.evaluate_codes_slot(7, codes_a)
+
+
+def test_augment8_gpu_wrapper_equals_host(resnet3):
+    from alphapig_amd.augment import augment8_gpu, get_equi_data
+    net, prm = resnet3
+    rs = np.random.RandomState(5)
+    planes = (rs.rand(7, 9, 15, 15) > 0.5).astype(np.float32)
+    pis = rs.rand(7, 225).astype(np.float32)
+    xo, po = augment8_gpu(net, planes, pis)
+    ext = get_equi_data([(planes[i], pis[i], 0.0) for i in range(7)], 15, 15)
+    np.testing.assert_array_equal(xo, np.stack([e[0] for e in ext]))
+    np.testing.assert_array_equal(po, np.stack([e[1] for e in ext]))

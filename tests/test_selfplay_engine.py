@@ -119,3 +119,19 @@ def test_run_steps_counts_and_limits():
     n = eng.run_steps(5)
     assert n == 30 and eng.stats["leaf_evals"] == 30       # one leaf per slot per round
     eng.close()
+
+
+def test_temperature_schedule_extension():
+    """BASELINE config 5's temperature schedule (a build-side extension; the reference is
+    constant-temp): from ply 4 on temp=1e-3, so pi collapses onto the most visited child."""
+    eng = SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=4, n_playout=30, temp=1.0, base_seed=99,
+                         n_threads=1, pipeline=2, forced_opening=False, temp_schedule=[(0, 1.0), (4, 1e-3)])
+    eps = eng.play_games(4)
+    for e in eps:
+        assert (e.pis[:4].max(axis=1) < 0.999).any()            # warm plies keep a spread
+        assert np.all(e.pis[4:].max(axis=1) > 0.999)            # cold plies are (near) one-hot
+    assert eng._temp_for(0) == 1.0 and eng._temp_for(7) == 1e-3
+    eng.close()
+    eng2 = SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=1, n_playout=5, temp_schedule=lambda ply: 0.5)
+    assert eng2._temp_for(3) == 0.5
+    eng2.close()
