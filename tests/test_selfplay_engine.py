@@ -129,7 +129,8 @@ def test_temperature_schedule_extension():
     eps = eng.play_games(4)
     for e in eps:
         assert (e.pis[:4].max(axis=1) < 0.999).any()            # warm plies keep a spread
-        assert np.all(e.pis[4:].max(axis=1) > 0.999)            # cold plies are (near) one-hot
+        cold = e.pis[4:]                                        # cold plies: all mass on the most visited child(ren)
+        assert np.all((cold < 1e-9) | (cold > cold.max(axis=1, keepdims=True) - 1e-9))
     assert eng._temp_for(0) == 1.0 and eng._temp_for(7) == 1e-3
     eng.close()
     eng2 = SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=1, n_playout=5, temp_schedule=lambda ply: 0.5)
