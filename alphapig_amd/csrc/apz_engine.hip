@@ -94,6 +94,8 @@ struct apz_engine {
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
     // profiling
     bool profiling = false;
+    int prof_stride = 1, prof_phase = 0;   // time every prof_stride-th forward only
+    bool prof_now = false;
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
     double k_ms[APZ_K_COUNT] = {0};
@@ -198,14 +200,14 @@ struct Timed {
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
     Timed(apz_engine* e_, int cls_) : e(e_), cls(cls_) {
-        if (e->profiling) {
+        if (e->profiling && e->prof_now) {
             a = get_event(e);
             b = get_event(e);
             hipEventRecord(a, e->stream);
         }
     }
     ~Timed() {
-        if (e->profiling) {
+        if (a) {
             hipEventRecord(b, e->stream);
             e->pending.push_back({cls, a, b});
         }
@@ -359,6 +361,7 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
     if (!e->loaded) return fail(APZ_E_STATE, "weights not loaded");
     if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
     if (n == 0) return APZ_OK;
+    e->prof_now = e->profiling && (e->prof_phase++ % e->prof_stride == 0);
     float* trunk = nullptr;
     int rc = run_trunk(e, planes, n, (int)e->convs.size() - 1, &trunk);
     if (rc) return rc;
@@ -445,9 +448,6 @@ void apz_destroy(apz_engine* e) {
         if (sl.h_codes) hipHostFree(sl.h_codes);
         if (sl.h_probs) hipHostFree(sl.h_probs);
         if (sl.h_values) hipHostFree(sl.h_values);
-        if (sl.d_probs) hipFree(sl.d_probs);
-        if (sl.d_values) hipFree(sl.d_values);
-        if (sl.d_codes) hipFree(sl.d_codes);
         if (sl.done) hipEventDestroy(sl.done);
     }
     void* host[] = {e->h_planes, e->h_probs, e->h_values, e->h_codes};
@@ -690,22 +690,23 @@ int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) 
     if (sl.busy) return fail(APZ_E_STATE, "slot still in flight: call apz_wait first");
     const size_t B = e->cfg.max_batch, hw = e->hw;
     if (!sl.h_codes) {
-        HIP_TRY(hipHostMalloc((void**)&sl.h_codes, B * e->code_stride));
-        HIP_TRY(hipHostMalloc((void**)&sl.h_probs, B * hw * sizeof(float)));
-        HIP_TRY(hipHostMalloc((void**)&sl.h_values, B * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&sl.d_codes, B * e->code_stride));
-        HIP_TRY(hipMalloc((void**)&sl.d_probs, B * hw * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&sl.d_values, B * sizeof(float)));
+        // Zero-copy slots: the 240-B/leaf codes and the 904-B/leaf results live in pinned,
+        // device-mapped host memory.  The encoder reads the codes and the head kernel writes
+        // probs/values straight over PCIe -- no blit kernels (and their ~25 us launch gaps)
+        // around the forward.
+        HIP_TRY(hipHostMalloc((void**)&sl.h_codes, B * e->code_stride, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&sl.h_probs, B * hw * sizeof(float), hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&sl.h_values, B * sizeof(float), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&sl.d_codes, sl.h_codes, 0));
+        HIP_TRY(hipHostGetDevicePointer((void**)&sl.d_probs, sl.h_probs, 0));
+        HIP_TRY(hipHostGetDevicePointer((void**)&sl.d_values, sl.h_values, 0));
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     std::memcpy(sl.h_codes, codes_host, (size_t)n * e->code_stride);
-    HIP_TRY(hipMemcpyAsync(sl.d_codes, sl.h_codes, (size_t)n * e->code_stride, hipMemcpyHostToDevice, e->stream));
     int rc = apz_encode_planes(e, sl.d_codes, n, e->cfg.c_in, e->planes);
     if (rc) return rc;
     rc = forward_dev(e, e->planes, n, sl.d_probs, sl.d_values, nullptr, nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(sl.h_probs, sl.d_probs, n * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(sl.h_values, sl.d_values, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipEventRecord(sl.done, e->stream));
     sl.n = n;
     sl.busy = true;
@@ -911,6 +912,8 @@ int apz_set_profiling(apz_engine* e, int on) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     resolve_pending(e);
     e->profiling = on != 0;
+    e->prof_stride = on > 1 ? on : 1;   // on = k > 1: sample every k-th forward
+    e->prof_phase = 0;
     for (int i = 0; i < APZ_K_COUNT; i++) {
         e->k_ms[i] = 0;
         e->k_cnt[i] = 0;

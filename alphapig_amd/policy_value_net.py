@@ -211,7 +211,8 @@ class PolicyValueNet(object):
         return float(ms[0])
 
     def set_profiling(self, on):
-        self._ck(self.L.apz_set_profiling(self._h, 1 if on else 0))
+        """on: False/0 off, True/1 every forward, k > 1 every k-th forward."""
+        self._ck(self.L.apz_set_profiling(self._h, int(on)))
 
     def kernel_time_ms(self, kernel_class):
         out = np.zeros(2, dtype=np.float32)

@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--full-games", type=int, default=0, help="play this many COMPLETE games per GPU "
                     "instead of timing --steps (measures games/s and mean plies directly; minutes)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
+    ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (gloo, stand-in evaluator from tests/fakenet.py, "
@@ -202,9 +203,13 @@ def main():
     if mean_plies is None:
         raise SystemExit("profiles/calibration_r01.json missing: run `python bench.py --full-games 1024` once")
 
+    import gc
     eng.run_steps(args.warmup)                       # W untimed warm-up steps
+    gc.collect()
+    gc.freeze()                                      # no cyclic-GC pauses inside the timed region
+    gc.disable()
     for ln in lanes:
-        ln.set_profiling(True)
+        ln.set_profiling(args.profile_every)
     p0, l0 = playouts_done(), eng.stats["leaf_evals"]
     host0, eval0 = eng.timers["host_s"], eng.timers["eval_s"]
     dist.barrier()

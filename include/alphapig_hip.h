@@ -130,8 +130,10 @@ int apz_conv3x3_bench(apz_engine *e, int layer, int n, int iters, int warmup, fl
 /* After a forward of batch n: copy the output activation of conv layer `layer`
  * ([n][C_out][H][W]) to host (per-layer parity tests). */
 int apz_layer_io(apz_engine *e, int layer, float *host_out, int64_t count);
-/* Per-kernel-class HIP-event timing over subsequent forwards: enable, then read
- * out[0] = total ms, out[1] = launches since enabling (resolved at apz_sync). */
+/* Per-kernel-class HIP-event timing over subsequent forwards: on = 1 times every forward,
+ * on = k > 1 every k-th forward (the event records cost a few us per kernel, so sampled timing
+ * keeps the measured run undisturbed); then read out[0] = total ms, out[1] = timed launches
+ * (resolved at apz_sync). */
 int apz_set_profiling(apz_engine *e, int on);
 int apz_kernel_time_ms(apz_engine *e, int kernel_class, float *out2);
 
