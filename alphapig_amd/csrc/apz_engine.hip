@@ -568,7 +568,10 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
         fold_bn(P, L.name, L.bn, L.mean_sfx, L.var_sfx, L.fix_gamma, L.cout, scale, shift);
         const float* w = P.at(L.name + "_weight");   // [cout][cin][3][3]
         const int n4 = L.cin_pad / 4, ncot = L.cout / 16;
-        std::vector<float> pk((size_t)ncot * n4 * 9 * 64, 0.f), bias(L.cout);
+        // trunk15_ring_kernel layers: [cot][c4][lane][12] (three 16-byte loads per lane and ci4 step);
+        // everything else: [cot][c4][tap][lane]
+        const bool x4 = e->ring && &L != &e->convs[0];
+        std::vector<float> pk((size_t)ncot * n4 * 64 * (x4 ? 12 : 9), 0.f), bias(L.cout);
         for (int cot = 0; cot < ncot; cot++)
             for (int c4 = 0; c4 < n4; c4++)
                 for (int tap = 0; tap < 9; tap++)
@@ -576,7 +579,10 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
                         const int co = cot * 16 + (lane & 15), ci = c4 * 4 + (lane >> 4);
                         float v = 0.f;
                         if (ci < L.cin) v = (float)((double)w[((size_t)co * L.cin + ci) * 9 + tap] * scale[co]);
-                        pk[(((size_t)cot * n4 + c4) * 9 + tap) * 64 + lane] = v;
+                        if (x4)
+                            pk[(((size_t)cot * n4 + c4) * 64 + lane) * 12 + tap] = v;
+                        else
+                            pk[(((size_t)cot * n4 + c4) * 9 + tap) * 64 + lane] = v;
                     }
         for (int o = 0; o < L.cout; o++) bias[o] = (float)shift[o];
         int rc = upload(&L.wpk, pk);

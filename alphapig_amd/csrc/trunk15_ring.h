@@ -48,7 +48,8 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// in / resid / out: [n][128][15][16] rows16 layout; wpk: [8][32][9][64] (cot, ci4, tap, lane)
+// in / resid / out: [n][128][15][16] rows16 layout; wpk: [8][32][64][12] (cot, ci4, lane, tap: 9 taps + 3 pad)
+// so that a lane fetches its nine weights of a ci4 step with three 16-byte loads
 // NW = waves per workgroup: 4 (one per SIMD, 2 channel tiles each) or 8 (two per SIMD, one channel
 // tile each: the second wave's MFMAs fill the first one's wait slots at iteration boundaries).
 template <bool RESID, int NW>
@@ -92,12 +93,16 @@ __global__ __launch_bounds__(64 * NW) void trunk15_ring_kernel(const float* __re
         for (int pl = 0; pl < PPW; pl++) issue_plane(g, pl);
     __syncthreads();   // emits vmcnt(0): chunks 0..2 of the first board have landed for every wave
 
-    const float* wbase = wpk + ((size_t)(wave * CT) * 32 * 9) * 64 + lane;
-    float a_cur[CT][9], a_nxt[CT][9];
+    const f32x4* wbase = reinterpret_cast<const f32x4*>(wpk) + ((size_t)(wave * CT) * 32 * 64 + lane) * 3;
+    float a_cur[CT][12], a_nxt[CT][12];
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) a_cur[ct][tap] = wbase[((size_t)ct * 32 * 9 + tap) * 64];
+        for (int v = 0; v < 3; v++) {
+            const f32x4 w4 = wbase[((size_t)ct * 32 * 64) * 3 + v];
+#pragma unroll
+            for (int u = 0; u < 4; u++) a_cur[ct][v * 4 + u] = w4[u];
+        }
 
     const int lane_off = q * T::LPS + j - 17;   // (row f-1, col j+kx-1) = f*16 + kx + (j - 17)
 
@@ -144,8 +149,11 @@ __global__ __launch_bounds__(64 * NW) void trunk15_ring_kernel(const float* __re
 #pragma unroll
                     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-                        for (int tap = 0; tap < 9; tap++)
-                            a_nxt[ct][tap] = wbase[(((size_t)ct * 32 + c4n) * 9 + tap) * 64];
+                        for (int v = 0; v < 3; v++) {
+                            const f32x4 w4 = wbase[(((size_t)ct * 32 + c4n) * 64) * 3 + v];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) a_nxt[ct][v * 4 + u] = w4[u];
+                        }
                     if (RESID && chunk == RES_CHUNK && c4l == 0) {
                         // all residual tiles of this board in ONE burst, chunks ahead of the epilogue:
                         // the compiler's per-iteration vmcnt(0) (LDS-DMA in flight) then stalls at most
