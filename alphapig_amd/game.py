@@ -173,3 +173,17 @@ class Game(object):
                 if is_shown:
                     print("Game end. Winner is", seat[winner]) if winner != -1 else print("Game end. Tie")
                 return winner
+
+    def start_self_play(self, player, is_shown=0, temp=1e-3, sgf_home=None, file_name=None):
+        """SGF replay used by the first phase of the reference pipeline (game.py:233-304):
+        -> (warning, winner, zip(states, mcts_probs, winners_z)).  MCTS self-play lives in
+        game_ai.Game_AI.start_self_play."""
+        from . import sgf
+        warning, winner, data = sgf.replay(self.board, sgf.get_data_from_files(file_name, sgf_home))
+        if warning:
+            return warning, None, None
+        player.reset_player()
+        if is_shown:
+            print("Game end. Winner is player:", winner)
+        return warning, winner, zip(*[list(x) for x in zip(*data)])
+

@@ -381,6 +381,57 @@ def capture_pure(mp, game):
     np.savez_compressed(os.path.join(OUT, "pure_mcts.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- SGF ingestion
+SGF_FILES = {
+    "0001_Blank_.sgf": "(;GM[4]FF[4]SZ[15];B[hh];W[ii];B[hi];W[ih];B[hj];W[jj];B[hk];W[kk];B[hl])\n\n",
+    "0002_White_.sgf": "(;FF[4]GM[4]SZ[15];B[aa];W[oo];B[ab];W[on];B[ba];W[om];B[ca];W[ol];B[da];W[ok])\n\n",
+    "0003_white_.sgf": "(;SZ[15];B[gg];W[hh])\n\n",
+    "0004_blank_.sgf": "(;SZ[15];B[gg];W[hh];B[gg];W[ii])\n\n",        # repeated cell -> warning
+}
+
+
+def capture_sgf(game):
+    """utils/sgf_dataIter.py cannot be imported whole under Python 3 (py2 print statements from
+    line 134 on), so only its parsing prefix (lines 1-66) is executed.  The parser drops the
+    last FOUR characters of the text it reads; the synthetic records end in "])" + two newlines
+    (Python 3 text mode would fold a "\r\n" into one character)."""
+    import tempfile
+    src = open(os.path.join(REF, "utils", "sgf_dataIter.py"), encoding="utf-8").read()
+    prefix = src[:src.index("def read_files(")]
+    mod = types.ModuleType("sgf_dataIter_prefix")
+    exec(compile(prefix, "sgf_dataIter.py[:read_files]", "exec"), mod.__dict__)
+    game.sgf_dataIter = mod                                    # what game.py:239 calls
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="sgf_golden_")
+    names = sorted(SGF_FILES)
+    for k, name in enumerate(names):
+        with open(os.path.join(tmp, name), "w", newline="") as f:
+            f.write(SGF_FILES[name])
+        rec = mod.get_data_from_files(name, tmp + os.sep)
+        out["f%d_name" % k] = np.array(name)
+        out["f%d_text" % k] = np.array(SGF_FILES[name])
+        out["f%d_winner" % k] = np.array(rec["winner"])
+        out["f%d_seq_list" % k] = np.array(rec["seq_list"])
+        out["f%d_seq_num" % k] = np.array(rec["seq_num_list"], dtype=np.int32)
+        b = game.Board(width=15, height=15, n_in_row=5)
+        g = game.Game(b)
+
+        class P(object):
+            def reset_player(self):
+                pass
+        warning, winner, data = g.start_self_play(P(), is_shown=0, sgf_home=tmp + os.sep, file_name=name)
+        out["f%d_warning" % k] = np.array(warning)
+        if not warning:
+            data = list(data)
+            out["f%d_states" % k] = np.stack([np.ascontiguousarray(d[0]) for d in data]).astype(np.uint8)
+            out["f%d_pis" % k] = np.stack([d[1] for d in data])
+            out["f%d_zs" % k] = np.array([d[2] for d in data])
+            out["f%d_replay_winner" % k] = np.array(winner)
+    out["n"] = np.array(len(names))
+    np.savez_compressed(os.path.join(OUT, "sgf.npz"), **out)
+    print("sgf:", len(names), "files")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -395,6 +446,7 @@ def main():
         "traces": lambda: capture_traces(mz, game),
         "selfplay": lambda: capture_selfplay(mz, game, game_ai),
         "pure": lambda: capture_pure(mp, game),
+        "sgf": lambda: capture_sgf(game),
     }
     for k, f in todo.items():
         if args.only in (None, k):
