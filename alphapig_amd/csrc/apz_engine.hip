@@ -91,6 +91,13 @@ struct apz_engine {
     std::mutex submit_lock;
     bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
     int act_ps = 0, act_rs = 0;
+    bool lds_attr_set[16] = {false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done, per kernel variant
+    int conv_lds_set[16] = {0};
+    // persistent sampler staging (apz_sample_moves_host)
+    int32_t* smp_vis = nullptr;
+    float* smp_pi = nullptr;
+    int32_t* smp_mv = nullptr;
+    size_t smp_cap = 0;
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
     // profiling
     bool profiling = false;
@@ -235,8 +242,8 @@ int launch_conv_r(apz_engine* e, const ConvLayer& L, const float* in, const floa
     int cchunk = L.cin_pad;
     while (cchunk > G::max_chunk()) cchunk = ((cchunk / 2) + 3) & ~3;
     const int lds = G::lds_bytes(cchunk);
-    static int configured_lds = -1;
     auto kern = apz::conv3x3_mfma_kernel<H, W, CT, RESID>;
+    int& configured_lds = e->conv_lds_set[(H == 15 ? 0 : 8) + (CT == 1 ? 0 : CT == 2 ? 2 : 4) + (RESID ? 1 : 0)];
     if (lds > configured_lds) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_lds = lds;
@@ -262,7 +269,7 @@ int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const floa
 template <int NW>
 int launch_trunk_ring_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
     using T = apz::Trunk15;
-    static bool configured = false;
+    bool& configured = e->lds_attr_set[NW == 8 ? 1 : 0];
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_ring_kernel<true, NW>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
@@ -289,7 +296,7 @@ int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const 
 template <int C4, int CIN>
 int launch_stem15_t(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
     constexpr int lds = apz::stem15_lds_bytes<C4>();
-    static bool configured = false;
+    bool& configured = e->lds_attr_set[C4 == 1 ? 2 : 3];
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void*)apz::stem15_kernel<C4, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
@@ -441,7 +448,7 @@ void apz_destroy(apz_engine* e) {
         if (l.bias) hipFree(l.bias);
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
-                   e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p};
+                   e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -781,22 +788,23 @@ int apz_sample_moves_host(apz_engine* e, const int32_t* visits_host, int g, floa
     std::lock_guard<std::mutex> guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t hw = e->hw, vb = (size_t)g * hw * sizeof(int32_t);
-    int32_t* d_vis = nullptr;
-    float* d_pi = nullptr;
-    int32_t* d_mv = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_vis, vb));
-    HIP_TRY(hipMalloc((void**)&d_pi, (size_t)g * hw * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&d_mv, (size_t)g * sizeof(int32_t)));
-    HIP_TRY(hipMemcpyAsync(d_vis, visits_host, vb, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(apz::root_sample_kernel, dim3(g), dim3(64), 0, e->stream, d_vis, d_pi, d_mv, g, (int)hw,
-                       1.0f / temp, alpha, eps, (unsigned long long)seed, (unsigned long long)step);
+    if ((size_t)g > e->smp_cap) {
+        if (e->smp_vis) hipFree(e->smp_vis);
+        if (e->smp_pi) hipFree(e->smp_pi);
+        if (e->smp_mv) hipFree(e->smp_mv);
+        e->smp_vis = nullptr; e->smp_pi = nullptr; e->smp_mv = nullptr; e->smp_cap = 0;
+        HIP_TRY(hipMalloc((void**)&e->smp_vis, vb));
+        HIP_TRY(hipMalloc((void**)&e->smp_pi, (size_t)g * hw * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&e->smp_mv, (size_t)g * sizeof(int32_t)));
+        e->smp_cap = g;
+    }
+    HIP_TRY(hipMemcpyAsync(e->smp_vis, visits_host, vb, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(apz::root_sample_kernel, dim3(g), dim3(64), 0, e->stream, e->smp_vis, e->smp_pi, e->smp_mv, g,
+                       (int)hw, 1.0f / temp, alpha, eps, (unsigned long long)seed, (unsigned long long)step);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(pi_host, d_pi, (size_t)g * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(moves_host, d_mv, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(pi_host, e->smp_pi, (size_t)g * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(moves_host, e->smp_mv, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    hipFree(d_vis);
-    hipFree(d_pi);
-    hipFree(d_mv);
     return APZ_OK;
 }
 
@@ -866,20 +874,19 @@ int apz_conv3x3_bench(apz_engine* e, int layer, int n, int iters, int warmup, fl
     if (L.residual)
         for (int i = 0; i < 3; i++)
             if (e->act[i] != in && e->act[i] != out) resid = e->act[i];
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
+    hipEvent_t a = get_event(e), b = get_event(e);   // pooled, destroyed with the engine
     int rc = APZ_OK;
     for (int i = 0; i < warmup && !rc; i++) rc = launch_conv(e, L, in, resid, out, n);
-    HIP_TRY(hipEventRecord(a, e->stream));
+    hipError_t he = hipEventRecord(a, e->stream);
     for (int i = 0; i < iters && !rc; i++) rc = launch_conv(e, L, in, resid, out, n);
-    HIP_TRY(hipEventRecord(b, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (he == hipSuccess) he = hipEventRecord(b, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, a, b));
-    hipEventDestroy(a);
-    hipEventDestroy(b);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, a, b);
+    e->free_events.push_back(a);
+    e->free_events.push_back(b);
     e->profiling = was;
+    if (he != hipSuccess) return fail(APZ_E_HIP, std::string("conv bench timing: ") + hipGetErrorString(he));
     if (rc) return rc;
     ms_out[0] = ms / iters;
     return APZ_OK;

@@ -69,8 +69,10 @@ class PolicyValueNet(object):
         return [(self.L.apz_param_name(self._h, i).decode(), int(self.L.apz_param_size(self._h, i)))
                 for i in range(n)]
 
-    def set_params(self, model_params):
+    def set_params(self, model_params, _keep_trainer=False):
         """model_params: {name: array} or the reference's (arg_params, aux_params) pair."""
+        if not _keep_trainer:
+            self._trainer = None          # externally supplied weights restart the optimiser state
         if isinstance(model_params, (tuple, list)) and len(model_params) == 2:
             merged = dict(model_params[0])
             merged.update(model_params[1])
@@ -201,8 +203,17 @@ class PolicyValueNet(object):
         probs, vals = self.forward_planes(state.reshape(1, self.channelnum, self.board_height, self.board_width))
         return zip(legal, probs[0][legal]), vals[0:1]
 
-    def train_step(self, *a, **k):
-        raise NotImplementedError("training is outside the hot path built here (SURVEY.md section 8f)")
+    def train_step(self, state_batch, mcts_probs, winner_batch, learning_rate):
+        """One optimiser step (policy_value_net_mxnet.py:282-299) -> (loss, entropy), then the new
+        weights are re-folded into the HIP evaluator like the reference re-syncs its predict
+        modules (:295-297).  INTERIM backward pass: PyTorch-ROCm autograd (alphapig_amd/train.py,
+        SURVEY.md 8f rank 1); the self-play hot path never touches it."""
+        from .train import TorchTrainer
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = TorchTrainer(self._params, self.net_kind, self._n_blocks, batch_size=self.batchsize)
+        loss, entropy = self._trainer.train_step(state_batch, mcts_probs, winner_batch, learning_rate)
+        self.set_params(self._trainer.get_params(), _keep_trainer=True)
+        return np.array([loss], dtype=np.float32), np.array([entropy], dtype=np.float32)
 
     # ---- measurement hooks
     def conv_bench(self, layer, n, iters=100, warmup=20):

@@ -116,3 +116,36 @@ def test_full_size_properties_1024_games():
         assert np.all(np.abs(root["q"]) <= 1.0 + 1e-6)
     eng.close()
     net.close()
+
+
+def test_closed_loop_selfplay_train_selfplay():
+    """One AlphaZero iteration on the GPU: HIP self-play -> augmentation -> (interim torch)
+    train_step -> re-folded weights in the HIP evaluator -> the evaluator now agrees with the
+    oracle forward on the UPDATED parameters."""
+    pytest.importorskip("torch")
+    from alphapig_amd.augment import get_equi_data
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    from alphapig_amd.selfplay import episodes_to_tuples
+    prm = weights.init_params("resnet", 8, 8, 9, 2, 64, seed=4, style="reference")
+    net = PolicyValueNet(8, 8, batch_size=64, n_blocks=2, n_filter=64, model_params=prm)
+    eng = SelfPlayEngine(net, 8, 8, 4, n_games=16, n_playout=20, temp=1.0, base_seed=11, n_threads=4, pipeline=2,
+                         forced_opening=False)
+    eps = eng.play_games(16)
+    states, pis, zs = episodes_to_tuples(eps, eng.pool)
+    data = get_equi_data(list(zip(states, pis, zs)), 8, 8)
+    rs = np.random.RandomState(0)
+    pick = rs.permutation(len(data))[:64]
+    batch = [data[i] for i in pick]
+    sb = np.stack([b[0] for b in batch]); pb = np.stack([b[1] for b in batch]); zb = np.array([b[2] for b in batch])
+    before = net.policy_value(sb)[0]
+    losses = [float(net.train_step(sb, pb, zb, 2e-3)[0][0]) for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    after = net.policy_value(sb)[0]
+    assert np.abs(after - before).max() > 1e-6                      # the evaluator really got new weights
+    new_prm = net.get_policy_param()
+    o = net_ref.forward(new_prm, sb, "resnet", 2, np.float64)
+    np.testing.assert_allclose(after, o[1], rtol=0, atol=2e-5)
+    eps2 = eng.play_games(eng.stats["games"] + 4)                   # and self-play goes on with them
+    assert len(eps2) >= 20
+    eng.close()
+    net.close()
