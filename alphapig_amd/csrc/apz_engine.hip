@@ -18,6 +18,7 @@
 #include "heads.h"
 #include "trunk15_ring.h"
 #include "sampler.h"
+#include "conv_train.h"
 
 namespace {
 
@@ -98,6 +99,8 @@ struct apz_engine {
     float* smp_pi = nullptr;
     int32_t* smp_mv = nullptr;
     size_t smp_cap = 0;
+    float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
+    bool wgrad_attr_set[2] = {false, false};
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
     // profiling
     bool profiling = false;
@@ -236,7 +239,7 @@ void resolve_pending(apz_engine* e) {
 
 template <int H, int W, int CT, bool RESID>
 int launch_conv_r(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n,
-                  int out_ps, int out_rs) {
+                  int out_ps, int out_rs, int relu = 1) {
     using G = apz::ConvGeo<H, W>;
     // keep channel chunks a power-of-two-ish split of Cin: 256 ch at 15x15 -> 2 x 128
     int cchunk = L.cin_pad;
@@ -252,7 +255,7 @@ int launch_conv_r(apz_engine* e, const ConvLayer& L, const float* in, const floa
     int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(lds, 1)));
     int grid = std::min(n, e->num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, resid, out, n, L.cin,
-                       L.cin_pad, cchunk, 1, out_ps, out_rs);
+                       L.cin_pad, cchunk, relu, out_ps, out_rs);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -448,7 +451,7 @@ void apz_destroy(apz_engine* e) {
         if (l.bias) hipFree(l.bias);
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
-                   e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv};
+                   e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -805,6 +808,108 @@ int apz_sample_moves_host(apz_engine* e, const int32_t* visits_host, int g, floa
     HIP_TRY(hipMemcpyAsync(pi_host, e->smp_pi, (size_t)g * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(moves_host, e->smp_mv, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return APZ_OK;
+}
+
+int64_t apz_conv3x3_packed_size(int cin_p, int cout_p) {
+    if (cin_p < 1 || cout_p < 16 || cout_p % 16) return -1;
+    return (int64_t)(cout_p / 16) * ((cin_p + 3) / 4) * 9 * 64;
+}
+
+namespace {
+struct StreamScope {      // run the engine's launch helpers on a caller-supplied stream
+    apz_engine* e;
+    hipStream_t saved;
+    StreamScope(apz_engine* e_, void* s) : e(e_), saved(e_->stream) {
+        if (s != APZ_ENGINE_STREAM) e->stream = (hipStream_t)s;   // NULL is a valid handle: the null stream
+    }
+    ~StreamScope() { e->stream = saved; }
+};
+}  // namespace
+
+int apz_conv3x3_pack(apz_engine* e, const void* w_dev, int cin, int cout, int transpose_flip, void* wpk_dev,
+                     void* stream) {
+    if (!e || !w_dev || !wpk_dev || cin < 1 || cout < 1) return fail(APZ_E_ARG, "bad argument");
+    const int co_p = transpose_flip ? cin : cout;
+    if (co_p % 16) return fail(APZ_E_UNSUPPORTED, "packed C_out must be a multiple of 16");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    const long total = apz_conv3x3_packed_size(transpose_flip ? cout : cin, co_p);
+    hipLaunchKernelGGL(apz::pack_conv3x3_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       e->stream, (const float*)w_dev, (float*)wpk_dev, cin, cout, transpose_flip);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_conv3x3_fwd(apz_engine* e, const void* x_dev, const void* wpk_dev, const void* bias_dev, void* y_dev, int n,
+                    int cin_p, int cout_p, int relu, void* stream) {
+    if (!e || !x_dev || !wpk_dev || !y_dev || n < 1 || cin_p < 1) return fail(APZ_E_ARG, "bad argument");
+    if (cout_p != 64 && cout_p != 128 && cout_p != 256)
+        return fail(APZ_E_UNSUPPORTED, "conv3x3_fwd: C_out must be 64, 128 or 256");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (!e->zeros256) {
+        HIP_TRY(hipMalloc((void**)&e->zeros256, 256 * sizeof(float)));
+        HIP_TRY(hipMemset(e->zeros256, 0, 256 * sizeof(float)));
+    }
+    StreamScope sc(e, stream);
+    ConvLayer L;
+    L.cin = cin_p;
+    L.cin_pad = (cin_p + 3) / 4 * 4;
+    L.cout = cout_p;
+    L.residual = false;
+    L.wpk = (float*)wpk_dev;
+    L.bias = bias_dev ? (float*)bias_dev : e->zeros256;
+    const int H = e->cfg.height, W = e->cfg.width, ct = cout_p / 64;
+    int rc = APZ_E_UNSUPPORTED;
+#define APZ_DENSE(HH, WW, CT) rc = launch_conv_r<HH, WW, CT, false>(e, L, (const float*)x_dev, nullptr, (float*)y_dev, n, HH * WW, WW, relu)
+    if (H == 15 && W == 15) {
+        if (ct == 1) APZ_DENSE(15, 15, 1); else if (ct == 2) APZ_DENSE(15, 15, 2); else APZ_DENSE(15, 15, 4);
+    } else if (H == 8 && W == 8) {
+        if (ct == 1) APZ_DENSE(8, 8, 1); else if (ct == 2) APZ_DENSE(8, 8, 2); else APZ_DENSE(8, 8, 4);
+    }
+#undef APZ_DENSE
+    L.wpk = nullptr;
+    L.bias = nullptr;
+    if (rc == APZ_E_UNSUPPORTED) return fail(rc, "conv3x3_fwd: unsupported board size");
+    return rc;
+}
+
+int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, int cin, int cout,
+                      void* stream) {
+    if (!e || !x_dev || !dy_dev || !dw_dev || n < 1 || cin < 1 || cout < 16 || cout % 16)
+        return fail(APZ_E_ARG, "bad argument (C_out must be a multiple of 16)");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    HIP_TRY(hipMemsetAsync(dw_dev, 0, (size_t)cout * cin * 9 * sizeof(float), e->stream));
+    const int H = e->cfg.height, W = e->cfg.width;
+    const int gx = cout / 16, gy = (cin + 63) / 64;
+    int slices = std::max(1, std::min(n, (e->num_cu * 2) / std::max(1, gx * gy)));
+    if (H == 15 && W == 15) {
+        using G = apz::WgradGeo<15, 15>;
+        if (!e->wgrad_attr_set[0]) {
+            HIP_TRY(hipFuncSetAttribute((const void*)apz::conv3x3_wgrad_kernel<15, 15>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+            e->wgrad_attr_set[0] = true;
+        }
+        slices = std::max(1, std::min(n, e->num_cu / std::max(1, gx * gy)));   // 85 KB LDS: one workgroup per CU
+        hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<15, 15>), dim3(gx, gy, slices), dim3(256), G::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
+    } else if (H == 8 && W == 8) {
+        using G = apz::WgradGeo<8, 8>;
+        if (!e->wgrad_attr_set[1]) {
+            HIP_TRY(hipFuncSetAttribute((const void*)apz::conv3x3_wgrad_kernel<8, 8>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+            e->wgrad_attr_set[1] = true;
+        }
+        hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<8, 8>), dim3(gx, gy, slices), dim3(256), G::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
+    } else {
+        return fail(APZ_E_UNSUPPORTED, "conv3x3_wgrad: unsupported board size");
+    }
+    HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
 

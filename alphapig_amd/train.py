@@ -34,11 +34,13 @@ def _torch():
 
 class TorchTrainer(object):
     def __init__(self, params, net_kind="resnet", n_blocks=10, batch_size=512, wd=1e-4, device=None,
-                 dtype=None, dropout=0.5, seed=0):
+                 dtype=None, dropout=0.5, seed=0, conv_backend="torch"):
         torch = _torch()
         self.torch = torch
         self.kind, self.n_blocks = net_kind, n_blocks
         self.batch_size, self.wd, self.dropout = batch_size, wd, dropout
+        # "hip": 3x3 convolutions (forward, dgrad, wgrad) on this repository's kernels (hipconv.py)
+        self.conv_backend = conv_backend
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
         self.device = torch.device(device)
@@ -67,9 +69,16 @@ class TorchTrainer(object):
         return F.batch_norm(x, rm, rv, gamma, self.p[name + "_beta"], training=train,
                             momentum=1.0 - BN_MOMENTUM, eps=BN_EPS)
 
+    def _conv(self, x, w, b, k):
+        if k == 3 and self.conv_backend == "hip":
+            from . import hipconv
+            if hipconv.supported(x, w):
+                return hipconv.conv3x3(x, w, b)
+        return self.torch.nn.functional.conv2d(x, w, b, padding=k // 2)
+
     def _conv_act(self, x, name, k, train):
         F = self.torch.nn.functional
-        y = F.conv2d(x, self.p[name + "_weight"], self.p[name + "_bias"], padding=k // 2)
+        y = self._conv(x, self.p[name + "_weight"], self.p[name + "_bias"], k)
         return F.relu(self._bn(y, name, True, "_mean", "_var", train))
 
     def forward(self, states, train=True):
@@ -79,9 +88,9 @@ class TorchTrainer(object):
             x = self._conv_act(x, "res_conv1", 3, train)
             for i in range(1, self.n_blocks + 1):
                 skip = x
-                y = F.conv2d(x, self.p["convA%d_weight" % i], self.p["convA%d_bias" % i], padding=1)
+                y = self._conv(x, self.p["convA%d_weight" % i], self.p["convA%d_bias" % i], 3)
                 y = F.relu(self._bn(y, "bnA%d" % i, False, "_moving_mean", "_moving_var", train))
-                y = F.conv2d(y, self.p["convB%d_weight" % i], self.p["convB%d_bias" % i], padding=1)
+                y = self._conv(y, self.p["convB%d_weight" % i], self.p["convB%d_bias" % i], 3)
                 y = self._bn(y, "bnB%d" % i, False, "_moving_mean", "_moving_var", train)
                 x = F.relu(y + skip)
         else:

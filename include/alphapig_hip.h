@@ -115,6 +115,26 @@ int apz_augment8(apz_engine *e, const void *planes_dev, const void *pi_dev, int 
 int apz_sample_moves_host(apz_engine *e, const int32_t *visits_host, int g, float temp, float alpha,
                           float eps, uint64_t seed, uint64_t step, float *pi_host, int32_t *moves_host);
 
+/* ---- training-side convolution primitives (hand-written forward, data- and
+ * weight-gradient of the 3x3 convolutions, callable on caller-owned dense NCHW float32 device
+ * tensors, e.g. from a torch.autograd.Function).  `stream` = the hipStream_t to launch on (NULL is
+ * the null stream, which is what torch.cuda.current_stream().cuda_stream reports by default);
+ * APZ_ENGINE_STREAM selects the engine's own stream.  Supported: boards 15x15 and 8x8; packed C_out in {64, 128, 256}.
+ *   apz_conv3x3_pack   w_dev [cout][cin][3][3] -> wpk_dev (apz_conv3x3_packed_size floats);
+ *                      transpose_flip=1 packs the weights of the data-gradient convolution
+ *                      dX = conv(dY, W'), W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
+ *   apz_conv3x3_fwd    y = conv(x, wpk) (+ bias_dev if not NULL) (ReLU if relu); channels are
+ *                      those of the PACKED convolution (cin_p inputs, cout_p outputs)
+ *   apz_conv3x3_wgrad  dw_dev [cout][cin][3][3] = sum_b x_b (*) dy_b (overwritten) */
+#define APZ_ENGINE_STREAM ((void *)(intptr_t)-1)
+int64_t apz_conv3x3_packed_size(int cin_p, int cout_p);
+int apz_conv3x3_pack(apz_engine *e, const void *w_dev, int cin, int cout, int transpose_flip,
+                     void *wpk_dev, void *stream);
+int apz_conv3x3_fwd(apz_engine *e, const void *x_dev, const void *wpk_dev, const void *bias_dev,
+                    void *y_dev, int n, int cin_p, int cout_p, int relu, void *stream);
+int apz_conv3x3_wgrad(apz_engine *e, const void *x_dev, const void *dy_dev, void *dw_dev, int n,
+                      int cin, int cout, void *stream);
+
 int apz_sync(apz_engine *e);
 void *apz_stream(apz_engine *e);
 void *apz_device_alloc(apz_engine *e, int64_t bytes);
