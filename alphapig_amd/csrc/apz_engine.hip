@@ -239,7 +239,7 @@ void resolve_pending(apz_engine* e) {
 
 template <int H, int W, int CT, bool RESID>
 int launch_conv_r(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n,
-                  int out_ps, int out_rs, int relu = 1) {
+                  int out_ps, int out_rs, int relu = 1, int cout_groups = 1) {
     using G = apz::ConvGeo<H, W>;
     // keep channel chunks a power-of-two-ish split of Cin: 256 ch at 15x15 -> 2 x 128
     int cchunk = L.cin_pad;
@@ -254,8 +254,8 @@ int launch_conv_r(apz_engine* e, const ConvLayer& L, const float* in, const floa
     // persistent grid: as many workgroups as fit at once, each loops over boards
     int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(lds, 1)));
     int grid = std::min(n, e->num_cu * per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, resid, out, n, L.cin,
-                       L.cin_pad, cchunk, relu, out_ps, out_rs);
+    hipLaunchKernelGGL(kern, dim3(grid, cout_groups), dim3(256), lds, e->stream, in, L.wpk, L.bias, resid, out, n, L.cin,
+                       L.cin_pad, cchunk, relu, out_ps, out_rs, L.cout);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -861,9 +861,14 @@ int apz_conv3x3_fwd(apz_engine* e, const void* x_dev, const void* wpk_dev, const
     L.residual = false;
     L.wpk = (float*)wpk_dev;
     L.bias = bias_dev ? (float*)bias_dev : e->zeros256;
-    const int H = e->cfg.height, W = e->cfg.width, ct = cout_p / 64;
+    const int H = e->cfg.height, W = e->cfg.width;
+    // small batches: split the output channels over 2 or 4 workgroups per board so that
+    // boards x groups covers the CUs (each group stages the board's input itself)
+    int groups = 1;
+    while (groups * 64 < cout_p && n * groups * 2 <= e->num_cu * 2 && n * groups < e->num_cu) groups *= 2;
+    const int ct = cout_p / 64 / groups;
     int rc = APZ_E_UNSUPPORTED;
-#define APZ_DENSE(HH, WW, CT) rc = launch_conv_r<HH, WW, CT, false>(e, L, (const float*)x_dev, nullptr, (float*)y_dev, n, HH * WW, WW, relu)
+#define APZ_DENSE(HH, WW, CT) rc = launch_conv_r<HH, WW, CT, false>(e, L, (const float*)x_dev, nullptr, (float*)y_dev, n, HH * WW, WW, relu, groups)
     if (H == 15 && W == 15) {
         if (ct == 1) APZ_DENSE(15, 15, 1); else if (ct == 2) APZ_DENSE(15, 15, 2); else APZ_DENSE(15, 15, 4);
     } else if (H == 8 && W == 8) {
@@ -878,14 +883,14 @@ int apz_conv3x3_fwd(apz_engine* e, const void* x_dev, const void* wpk_dev, const
 
 int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, int cin, int cout,
                       void* stream) {
-    if (!e || !x_dev || !dy_dev || !dw_dev || n < 1 || cin < 1 || cout < 16 || cout % 16)
-        return fail(APZ_E_ARG, "bad argument (C_out must be a multiple of 16)");
+    if (!e || !x_dev || !dy_dev || !dw_dev || n < 1 || cin < 1 || cout < 32 || cout % 32)
+        return fail(APZ_E_ARG, "bad argument (C_out must be a multiple of 32)");
     std::lock_guard<std::mutex> guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     HIP_TRY(hipMemsetAsync(dw_dev, 0, (size_t)cout * cin * 9 * sizeof(float), e->stream));
     const int H = e->cfg.height, W = e->cfg.width;
-    const int gx = cout / 16, gy = (cin + 63) / 64;
+    const int gx = cout / 32, gy = (cin + 63) / 64;
     int slices = std::max(1, std::min(n, (e->num_cu * 2) / std::max(1, gx * gy)));
     if (H == 15 && W == 15) {
         using G = apz::WgradGeo<15, 15>;

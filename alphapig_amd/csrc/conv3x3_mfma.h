@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
                                                            const float* __restrict__ resid,
                                                            float* __restrict__ out, int n, int cin,
                                                            int cin_pad, int cchunk, int relu,
-                                                           int out_ps, int out_rs) {
+                                                           int out_ps, int out_rs, int cout_total) {
     using G = ConvGeo<H, W>;
     constexpr int HW = H * W;
     extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     const int wave = tid >> 6;
     const int q = lane >> 4;          // k slot (input channel within the group of 4)
     const int j = lane & 15;          // pixel lane
-    const int cout = 64 * CT;
+    // gridDim.y > 1: this workgroup computes output channels [blockIdx.y*64*CT, +64*CT) of cout_total
+    // (small batches: two or four workgroups per board keep all CUs busy)
+    const int cout = cout_total;
+    const int wtile0 = blockIdx.y * 4 * CT + wave * CT;   // first 16-channel tile of this wave
     const int n4 = cin_pad >> 2;
     const int lds_floats = cchunk * G::PS + G::SLACK;   // cchunk: channels resident at once
 
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 
             // A fragments of this wave's CT channel tiles, double-buffered over ci4
             const int c4_lo = c0 >> 2, c4_hi = min(cin_pad, c0 + cchunk) >> 2;
-            const float* wbase = wpk + ((size_t)(wave * CT) * n4 * 9) * 64 + lane;
+            const float* wbase = wpk + ((size_t)wtile0 * n4 * 9) * 64 + lane;
             float a_cur[CT][9], a_nxt[CT][9];
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
         const float* rsd = RESID ? resid + (size_t)b * cout * out_ps : nullptr;
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
-            const int co0 = (wave * CT + ct) * 16 + q * 4;
+            const int co0 = (wtile0 + ct) * 16 + q * 4;
             float bv[4];
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) bv[rr] = bias[co0 + rr];

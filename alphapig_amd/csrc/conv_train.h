@@ -8,11 +8,11 @@
 //                         dY[b][co][y][x] * X[b][ci][y+ky-1][x+kx-1]
 //                         as fp32 MFMA: D[16 co][16 ci] += A[16 co][4 px] * B[4 px][16 ci] per tap.
 //
-// wgrad mapping: a workgroup owns ONE 16-channel tile of C_out and up to 64 input channels (one
-// 16-channel tile per wave) for a slice of the batch; a wave keeps 9 accumulator tiles (one per
-// tap, 36 registers).  Per board it stages dY[16][H*W] and X[64][(H+2) x (W+1) padded] in LDS; a
-// k-step is 4 consecutive pixels: the A fragment (dY) is read once per k-step and reused by the
-// nine taps, the B fragment is the input at the tap's shift (zero halo in the padded tile).
+// wgrad mapping: a workgroup owns TWO 16-channel tiles of C_out and up to 64 input channels (one
+// 16-channel tile per wave) for a slice of the batch; a wave keeps 2 x 9 accumulator tiles (one
+// per C_out tile and tap, 72 registers).  Per board it stages dY[32][H*W] and X[64][(H+2) x (W+1)
+// padded] in LDS; a k-step is 4 consecutive pixels: the A fragments (dY) are read once per k-step
+// and reused by the nine taps, the B fragment is the input at the tap's shift (zero halo).
 // Plane strides are odd multiples chosen so the 16 channel lanes of a fragment hit 16 distinct
 // banks.  Partial sums of the batch slices are combined with float atomics (dW is zeroed by the
 // launcher), so the summation order -- and the last bits -- vary from run to run.
@@ -60,75 +60,152 @@ struct WgradGeo {
     static constexpr int XPS = XPLANE | 1;                          // odd: 16 channel lanes -> 16 banks
     static constexpr int KSTEPS = (HW + 3) / 4;
     static constexpr int YPS = (KSTEPS * 4) | 1;                    // odd, >= padded pixel count
-    static constexpr int LDS_FLOATS = 64 * XPS + 16 * YPS + 64;
+    static constexpr int COT = 2;                                   // 16-channel C_out tiles per workgroup
+    static constexpr int TILE_FLOATS = 64 * XPS + COT * 16 * YPS + 64;
+    static constexpr int EPI_FLOATS = COT * 16 * (64 * 9 + 1);      // epilogue staging [co][ci*9 (+1)]
+    static constexpr int LDS_FLOATS = TILE_FLOATS > EPI_FLOATS ? TILE_FLOATS : EPI_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
 // x [n][cin][H][W], dy [n][cout][H][W] dense; dw [cout][cin][3][3] (pre-zeroed, atomically added).
-// grid: (cout/16, ceil(cin/64), batch slices)
+// grid: (cout/32, ceil(cin/64), batch slices).  The staged input tile (64 channels) is shared by
+// the workgroup's two C_out tiles; a wave holds 2 x 9 accumulator tiles (72 registers).
+// Staging is software-pipelined through registers: the NEXT board's 16-byte pieces are loaded
+// before this board's MFMA loop and scattered into LDS after it, so HBM/L2 latency hides behind
+// ~1000 MFMAs per wave.  The epilogue transposes the accumulators through LDS so that every
+// atomic wave-instruction adds 64 consecutive floats of one dW row.
 template <int H, int W>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dw, int n, int cin, int cout) {
     using G = WgradGeo<H, W>;
-    constexpr int HW = G::HW;
+    constexpr int HW = G::HW, COT = G::COT;
+    constexpr int XV = (64 * HW / 4 + 255) / 256;        // float4 pieces per thread: input tile
+    constexpr int YV = (COT * 16 * HW / 4 + 255) / 256;  // dY tile
+    static_assert((64 * HW) % 4 == 0 && (COT * 16 * HW) % 4 == 0, "tiles are whole float4s");
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* xt = sm + 32;                    // [64][XPS], origin shifted so (row -1, col -1) is in bounds
-    float* yt = sm + 32 + 64 * G::XPS;      // [16][YPS]
+    float* xt = sm + 32;                    // [64][XPS]
+    float* yt = sm + 32 + 64 * G::XPS;      // [COT*16][YPS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, j = lane & 15;
-    const int cot = blockIdx.x;
+    const int co0 = blockIdx.x * 16 * COT;
     const int ci0 = blockIdx.y * 64;
     const int nci = min(64, cin - ci0);     // input channels of this workgroup (may be < 64)
+    const int nx4 = nci * HW / 4 + ((nci * HW) % 4 ? 1 : 0);
 
-    for (int i = tid; i < G::LDS_FLOATS; i += 256) sm[i] = 0.f;   // halos / unused channels / tail pixels stay 0
+    for (int i = tid; i < G::TILE_FLOATS; i += 256) sm[i] = 0.f;  // halos / unused channels / tail pixels stay 0
 
-    f32x4 acc[9];
+    f32x4 acc[COT][9];
 #pragma unroll
-    for (int t = 0; t < 9; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < COT; c++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const float* arow = yt + j * G::YPS + q;                 // A: co = j, pixel = 4s + q
+    const float* arow = yt + j * G::YPS + q;                 // A: co = j (+16 per tile), pixel = 4s + q
     const float* brow = xt + (wave * 16 + j) * G::XPS;       // B: ci = wave*16 + j
 
+    f32x4 px[XV], py[YV];
+    auto fetch = [&](int b) {               // global -> registers (16-byte pieces; tiles are 16-B aligned)
+        const f32x4* xb = reinterpret_cast<const f32x4*>(x + ((size_t)b * cin + ci0) * HW);
+        const f32x4* yb = reinterpret_cast<const f32x4*>(dy + ((size_t)b * cout + co0) * HW);
+        const bool xal = ((((size_t)b * cin + ci0) * HW) & 3) == 0 && (nci * HW) % 4 == 0;
+#pragma unroll
+        for (int u = 0; u < XV; u++) {
+            const int v = tid + u * 256;
+            px[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (b < n && v < nx4) {
+                if (xal) {
+                    px[u] = xb[v];
+                } else {                    // C_in = 9 stem: planes are not 16-byte aligned
+                    const float* xs = x + ((size_t)b * cin + ci0) * HW;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (v * 4 + e < nci * HW) px[u][e] = xs[v * 4 + e];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < YV; u++) {
+            const int v = tid + u * 256;
+            py[u] = (b < n && v < COT * 16 * HW / 4) ? yb[v] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto scatter = [&]() {                  // registers -> padded LDS tiles
+#pragma unroll
+        for (int u = 0; u < XV; u++) {
+            const int v = tid + u * 256;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int idx = v * 4 + e;
+                if (idx < nci * HW) {
+                    const int c = idx / HW, rem = idx - c * HW;
+                    const int yy = rem / W, xx = rem - yy * W;
+                    xt[c * G::XPS + (yy + 1) * G::RS + xx + 1] = px[u][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < YV; u++) {
+            const int v = tid + u * 256;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int idx = v * 4 + e;
+                if (idx < COT * 16 * HW) {
+                    const int c = idx / HW;
+                    yt[c * G::YPS + idx - c * HW] = py[u][e];
+                }
+            }
+        }
+    };
+
+    fetch(blockIdx.z);
     for (int b = blockIdx.z; b < n; b += gridDim.z) {
+        __syncthreads();                     // previous board's tiles fully consumed (and the zero fill done)
+        scatter();
         __syncthreads();
-        const float* xb = x + ((size_t)b * cin + ci0) * HW;
-        for (int idx = tid; idx < nci * HW; idx += 256) {
-            const int c = idx / HW, rem = idx - c * HW;
-            const int yy = rem / W, xx = rem - yy * W;
-            xt[c * G::XPS + (yy + 1) * G::RS + xx + 1] = xb[idx];
-        }
-        const float* yb = dy + ((size_t)b * cout + cot * 16) * HW;
-        for (int idx = tid; idx < 16 * HW; idx += 256) {
-            const int c = idx / HW, rem = idx - c * HW;
-            yt[c * G::YPS + rem] = yb[idx];
-        }
-        __syncthreads();
+        fetch(b + gridDim.z);                // in flight during the MFMA loop below
         if (wave * 16 < nci) {               // wave-uniform: this wave's 16 input channels exist
+            int yy = 0, xx = q;              // pixel 4s + q as (row, col), advanced incrementally (W >= 4)
+#pragma unroll 3
             for (int s = 0; s < G::KSTEPS; s++) {
-                const float a = arow[4 * s];
-                int p = 4 * s + q;
-                p = p < HW ? p : HW - 1;     // tail lanes: dY there is 0, any in-bounds address will do
-                const int yy = p / W, xx = p - yy * W;
-                const float* bp = brow + yy * G::RS + xx;    // (yy + ky) * RS + xx + kx, origin (-1,-1)
+                float a[COT];
+#pragma unroll
+                for (int c = 0; c < COT; c++) a[c] = arow[c * 16 * G::YPS + 4 * s];
+                const int yc = yy < H ? yy : H - 1;          // tail lanes: dY there is 0, stay in bounds
+                const float* bp = brow + yc * G::RS + xx;
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-                    for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[ky * G::RS + kx], acc[ky * 3 + kx],
-                                                                                0, 0, 0);
+                    for (int kx = 0; kx < 3; kx++) {
+                        const float bv = bp[ky * G::RS + kx];
+#pragma unroll
+                        for (int c = 0; c < COT; c++)
+                            acc[c][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bv, acc[c][ky * 3 + kx], 0, 0, 0);
+                    }
+                xx += 4;
+                if (xx >= W) { xx -= W; yy++; }
             }
         }
     }
-    // D lane l, reg r: co = cot*16 + 4q + r, ci = ci0 + wave*16 + j
-    const int ci = ci0 + wave * 16 + j;
-    if (wave * 16 < nci && ci < cin) {
+    // ---- epilogue: accumulators -> LDS as [co 32][ci 64][9] (row = 576 floats, +1 pad), then every
+    // wave adds whole rows: 64 consecutive floats per atomic instruction.
+    // D lane l, reg r: co = 16c + 4q + r, ci = wave*16 + j
+    __syncthreads();
+    constexpr int ROW = 64 * 9 + 1;
+    static_assert(32 * ROW <= G::LDS_FLOATS, "epilogue staging fits the tile memory");
+    float* st = sm;
+    if (wave * 16 < nci) {
 #pragma unroll
-        for (int t = 0; t < 9; t++)
+        for (int c = 0; c < COT; c++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int co = cot * 16 + q * 4 + r;
-                atomicAdd(dw + ((size_t)co * cin + ci) * 9 + t, acc[t][r]);
-            }
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) st[(c * 16 + q * 4 + r) * ROW + (wave * 16 + j) * 9 + t] = acc[c][t][r];
+    }
+    __syncthreads();
+    const int rowlen = nci * 9;              // valid floats of a staged row
+    for (int row = wave; row < COT * 16; row += 4) {
+        float* drow = dw + ((size_t)(co0 + row) * cin + ci0) * 9;
+        for (int i = lane; i < rowlen; i += 64) atomicAdd(drow + i, st[row * ROW + i]);
     }
 }
 
