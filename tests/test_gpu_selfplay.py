@@ -149,3 +149,20 @@ def test_closed_loop_selfplay_train_selfplay():
     assert len(eps2) >= 20
     eng.close()
     net.close()
+
+
+def test_train_pipeline_runs_a_few_batches():
+    """TrainPipeline (reference train_mxnet.py:38-300 wired onto the engine): a few batches of
+    self-play + update + one arena evaluation complete and produce finite numbers."""
+    pytest.importorskip("torch")
+    from alphapig_amd.pipeline import TrainPipeline
+    conf = dict(board_width=8, board_height=8, n_in_row=4, learn_rate=2e-3, lr_multiplier=1.0, temp=1.0,
+                n_playout=30, c_puct=5, buffer_size=5000, batch_size=64, epochs=2, kl_targ=0.02, check_freq=3,
+                pure_mcts_playout_num=30, game_batch_num=3, play_batch_size=2, concurrent_games=16, n_blocks=1,
+                n_filter=64, eval_games=4, model_dir="/tmp/apz_models_test")
+    tp = TrainPipeline(conf, seed=3)
+    hist = tp.run()
+    assert len(hist) == 3 and "win_ratio" in hist[-1] and 0.0 <= hist[-1]["win_ratio"] <= 1.0
+    assert any("loss" in h and np.isfinite(h["loss"]) for h in hist)
+    assert tp._taken == 6 and len(tp.data_buffer) > 0
+    tp.close()
