@@ -65,7 +65,8 @@ class TrainPipeline(object):
             device=device, seed=seed)
         self.engine = SelfPlayEngine(self.policy_value_net, self.board_width, self.board_height, self.n_in_row,
                                      n_games=concurrent, n_playout=self.n_playout, c_puct=self.c_puct,
-                                     temp=self.temp, base_seed=seed, pipeline=2)
+                                     temp=self.temp, base_seed=seed, pipeline=2,
+                                     forced_opening=(self.board_width == 15 and self.board_height == 15))
         self._taken = 0
         self._rng = random.Random(seed)
         self.episode_len = 0

@@ -67,6 +67,10 @@ class SelfPlayEngine(object):
         self.temp_schedule = temp_schedule
         self.base_seed = int(base_seed)
         self.noise_alpha, self.noise_eps = noise_alpha, noise_eps
+        if forced_opening and (board_width != 15 or board_height != 15):
+            # the reference's opening book is written for the 15-wide board (game_ai.py:77-78);
+            # on any other board its moves are illegal and the reference raises at list.remove
+            raise ValueError("forced_opening needs a 15x15 board; pass forced_opening=False")
         self.forced_opening = forced_opening
         self.pipeline = max(1, int(pipeline))
         # multi-GPU sharding: this engine owns global games offset, offset+stride, ... (dist.py)

@@ -133,6 +133,13 @@ def test_temperature_schedule_extension():
         assert np.all((cold < 1e-9) | (cold > cold.max(axis=1, keepdims=True) - 1e-9))
     assert eng._temp_for(0) == 1.0 and eng._temp_for(7) == 1e-3
     eng.close()
-    eng2 = SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=1, n_playout=5, temp_schedule=lambda ply: 0.5)
+    eng2 = SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=1, n_playout=5, temp_schedule=lambda ply: 0.5,
+                          forced_opening=False)
     assert eng2._temp_for(3) == 0.5
     eng2.close()
+
+
+def test_forced_opening_book_needs_15x15():
+    import pytest
+    with pytest.raises(ValueError):
+        SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=1, n_playout=5)
