@@ -165,7 +165,7 @@ class PolicyValueNet(object):
         """submit + wait on one slot; safe to call from one host thread per slot."""
         c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.code_stride)
         n = c.shape[0]
-        if n > self.batchsize:
+        if n > self.batchsize or n == 0:
             return self.evaluate_codes(c)
         probs = np.empty((n, self.hw), dtype=np.float32)
         vals = np.empty(n, dtype=np.float32)

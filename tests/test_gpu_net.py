@@ -265,3 +265,35 @@ def test_augment8_gpu_wrapper_equals_host(resnet3):
     ext = get_equi_data([(planes[i], pis[i], 0.0) for i in range(7)], 15, 15)
     np.testing.assert_array_equal(xo, np.stack([e[0] for e in ext]))
     np.testing.assert_array_equal(po, np.stack([e[1] for e in ext]))
+
+
+def test_empty_and_ragged_batches(resnet3):
+    """n = 0 batches are accepted everywhere; ragged sizes around the 16-board head tile and the
+    batch limit give the same rows as single evaluations."""
+    net, prm = resnet3
+    p, v = net.forward_planes(np.zeros((0, 9, 15, 15), np.float32))
+    assert p.shape == (0, 225) and v.shape == (0,)
+    p, v = net.evaluate_codes(np.zeros((0, net.code_stride), np.uint8))
+    assert p.shape == (0, 225) and v.shape == (0,)
+    codes, planes = random_positions(64, 15, seed=55)
+    ref_p, ref_v = net.forward_planes(planes)
+    for n in (1, 15, 16, 17, 31, 33, 63, 64):
+        p, v = net.forward_planes(planes[:n])
+        np.testing.assert_array_equal(p, ref_p[:n])
+        np.testing.assert_array_equal(v, ref_v[:n])
+        p, v = net.evaluate_codes_slot(n % 4, codes[:n])
+        np.testing.assert_array_equal(p, ref_p[:n])
+    # an empty board and a full board are valid inputs
+    from alphapig_amd.game import Board
+    b = Board(width=15, height=15, n_in_row=5)
+    b.init_board()
+    pe, ve = net.evaluate_codes(b.position_codes()[None])
+    assert abs(pe.sum() - 1) < 1e-5 and -1 <= ve[0] <= 1
+    full = np.arange(225)
+    rs = np.random.RandomState(2)
+    rs.shuffle(full)
+    for m in full:
+        b.do_move(int(m))
+    pf, vf = net.evaluate_codes(b.position_codes()[None])
+    ref = net_ref.forward(prm, np.ascontiguousarray(b.current_state())[None], "resnet", 3)
+    np.testing.assert_allclose(pf, ref[1], rtol=0, atol=2e-5)

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""BASELINE.md section 3 table (B1/B2/B4): BASELINE.json configs 1-3 on this machine.
+
+  config 1  8x8, 4-in-row, n_playout=100, pure-MCTS rollouts, CPU only: the sequential oracle
+            (python restatement of mcts_pure.py) vs the native host library, same seeds
+  config 2  8x8, 4-in-row, n_playout=200, simple net, 64 concurrent games on the GPU
+  config 3  15x15, 5-in-row, n_playout=400, 10-block residual net, 1024 concurrent games (short slice)
+Prints one JSON object.  Run on the GPU box:  python tools/config_table.py
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from alphapig_amd import mcts_pure, weights  # noqa: E402
+from alphapig_amd.game import Board, Game  # noqa: E402
+
+
+def config1(n_games=4):
+    from oracle.board_ref import RefBoard
+    from oracle.mcts_ref import RefPureMCTSPlayer
+    out = {}
+    # native
+    t = time.perf_counter()
+    plies = 0
+    for g in range(n_games):
+        b = Board(width=8, height=8, n_in_row=4)
+        np.random.seed(9000 + g)
+        Game(b).start_play(mcts_pure.MCTSPlayer(5, 100), mcts_pure.MCTSPlayer(5, 100), start_player=g % 2, is_shown=0)
+        plies += len(b.history)
+    dt = time.perf_counter() - t
+    out["native_host_library"] = {"games_per_s": n_games / dt, "playouts_per_s": plies * 100 / dt, "cores": 1}
+    # sequential python oracle (same algorithm as the reference's mcts_pure.py)
+    t = time.perf_counter()
+    plies2 = 0
+    for g in range(2):
+        b = RefBoard(8, 8, 4)
+        b.init_board(g % 2)
+        rs = np.random.RandomState(9000 + g)
+        players = {1: RefPureMCTSPlayer(5, 100, rs), 2: RefPureMCTSPlayer(5, 100, rs)}
+        while True:
+            b.do_move(players[b.get_current_player()].get_action(b))
+            if b.game_end()[0]:
+                break
+        plies2 += len(b.move_list)
+    dt2 = time.perf_counter() - t
+    out["python_oracle"] = {"games_per_s": 2 / dt2, "playouts_per_s": plies2 * 100 / dt2, "cores": 1}
+    return out
+
+
+def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10):
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    from alphapig_amd.selfplay import SelfPlayEngine
+    prm = weights.init_params(kind, w, w, 9, n_blocks, 128, seed=0, style="bench")
+    net = PolicyValueNet(w, w, batch_size=max(16, G // 2), n_blocks=n_blocks, n_filter=128, model_params=prm,
+                         net_kind=kind)
+    eng = SelfPlayEngine(net, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=77, pipeline=2,
+                         forced_opening=(w == 15))
+    eng.run_steps(30)
+    net.sync()
+    l0, m0, g0, p0 = eng.stats["leaf_evals"], eng.stats["moves"], eng.stats["games"], eng.stats["plies"]
+    t = time.perf_counter()
+    eng.run_steps(steps)
+    net.sync()
+    dt = time.perf_counter() - t
+    res = {"concurrent_games": G, "steps": steps, "leaf_evals_per_s": (eng.stats["leaf_evals"] - l0) / dt,
+           "moves_per_s": (eng.stats["moves"] - m0) / dt, "games_finished": eng.stats["games"] - g0,
+           "ms_per_step": 1e3 * dt / steps}
+    if eng.stats["games"] - g0 > 0:
+        res["mean_plies_finished"] = (eng.stats["plies"] - p0) / (eng.stats["games"] - g0)
+        res["games_per_s_finished"] = (eng.stats["games"] - g0) / dt
+    eng.close()
+    net.close()
+    return res
+
+
+def main():
+    out = {"config1_pure_mcts_8x8_n100_cpu": config1()}
+    out["config2_simple_net_8x8_n200_64games"] = gpu_config("simple", 8, 4, 200, 64, 6000)
+    out["config3_resnet10_15x15_n400_1024games"] = gpu_config("resnet", 15, 5, 400, 1024, 400)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
