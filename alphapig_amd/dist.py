@@ -15,14 +15,15 @@ import os
 import numpy as np
 
 
-def init(backend=None, device_index=None):
-    """Initialise torch.distributed from the torchrun environment.  -> (rank, world, local_rank)"""
+def init(backend=None, device_index=None, force=False):
+    """Initialise torch.distributed from the torchrun environment.  -> (rank, world, local_rank)
+    force=True creates the process group even for a single rank (exercises RCCL on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -81,7 +82,7 @@ def all_gather_tuples(codes, pis, zs):
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     pis = np.ascontiguousarray(pis, dtype=np.float32)
     zs = np.ascontiguousarray(zs, dtype=np.float32).reshape(-1)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return codes, pis, zs
     world = dist.get_world_size()
     dev = _device()

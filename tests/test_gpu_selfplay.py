@@ -166,3 +166,17 @@ def test_train_pipeline_runs_a_few_batches():
     assert any("loss" in h and np.isfinite(h["loss"]) for h in hist)
     assert tp._taken == 6 and len(tp.data_buffer) > 0
     tp.close()
+
+
+def test_rccl_collectives_world_size_1():
+    """backend nccl (= RCCL) with one rank on the GPU: count gather + padded tuple all-gather."""
+    pytest.importorskip("torch")
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(here, "_rccl_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world_size=1 ok" in r.stdout, r.stdout[-2000:]
