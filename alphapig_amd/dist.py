@@ -18,12 +18,16 @@ import numpy as np
 def init(backend=None, device_index=None, force=False):
     """Initialise torch.distributed from the torchrun environment.  -> (rank, world, local_rank)
     force=True creates the process group even for a single rank (exercises RCCL on a 1-GPU box)."""
-    import torch
-    import torch.distributed as dist
+    global _ACTIVE
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if (world > 1 or force) and not dist.is_initialized():
+    if world <= 1 and not force:
+        return rank, world, local            # single process: torch is never imported
+    import torch
+    import torch.distributed as dist
+    _ACTIVE = True
+    if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -31,6 +35,9 @@ def init(backend=None, device_index=None, force=False):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+_ACTIVE = False        # a process group was requested: only then do the helpers below touch torch
 
 
 def shard_indices(total_games, rank, world):
@@ -48,12 +55,16 @@ def _device():
 
 
 def barrier():
+    if not _ACTIVE:
+        return
     import torch.distributed as dist
     if dist.is_initialized():
         dist.barrier()
 
 
 def all_reduce_max(x):
+    if not _ACTIVE:
+        return float(x)
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -64,6 +75,8 @@ def all_reduce_max(x):
 
 
 def all_reduce_sum(x):
+    if not _ACTIVE:
+        return float(x)
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -77,11 +90,13 @@ def all_gather_tuples(codes, pis, zs):
     """codes uint8 [T, S], pis float32 [T, HW], zs float32 [T] of this rank ->
     the concatenation over ranks in rank order (every rank gets everything).
     Variable T per rank: counts are gathered first, payloads are padded to max T."""
-    import torch
-    import torch.distributed as dist
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     pis = np.ascontiguousarray(pis, dtype=np.float32)
     zs = np.ascontiguousarray(zs, dtype=np.float32).reshape(-1)
+    if not _ACTIVE:
+        return codes, pis, zs
+    import torch
+    import torch.distributed as dist
     if not dist.is_initialized():
         return codes, pis, zs
     world = dist.get_world_size()
