@@ -17,6 +17,7 @@
 #include "conv3x3_mfma.h"
 #include "heads.h"
 #include "trunk15_ring.h"
+#include "trunk15_wino.h"
 #include "sampler.h"
 #include "conv_train.h"
 
@@ -51,6 +52,7 @@ struct ConvLayer {
     int cin, cin_pad, cout;
     bool residual;          // add the block input before ReLU
     float* wpk = nullptr;
+    float* upk = nullptr;   // trunk15_wino_kernel: transformed weights G g G^T in MFMA fragment order
     float* bias = nullptr;
 };
 
@@ -101,6 +103,7 @@ struct apz_engine {
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     bool wgrad_attr_set[2] = {false, false};
+    bool wino = true;       // trunk layers through trunk15_wino_kernel (APZ_TRUNK_KERNEL=ring: the direct kernel)
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
     // profiling
     bool profiling = false;
@@ -291,7 +294,29 @@ int launch_trunk_ring_t(apz_engine* e, const ConvLayer& L, const float* in, cons
     return APZ_OK;
 }
 
+int launch_trunk_wino(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Wino15;
+    bool& configured = e->lds_attr_set[4];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino_kernel<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        configured = true;
+    }
+    const int grid = std::min(n, e->num_cu);   // one persistent workgroup per CU (register- and LDS-bound)
+    if (resid)
+        hipLaunchKernelGGL((apz::trunk15_wino_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk,
+                           L.bias, resid, out, n);
+    else
+        hipLaunchKernelGGL((apz::trunk15_wino_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk,
+                           L.bias, resid, out, n);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    if (e->wino && L.upk) return launch_trunk_wino(e, L, in, resid, out, n);
     if (e->trunk_waves == 8) return launch_trunk_ring_t<8>(e, L, in, resid, out, n);
     return launch_trunk_ring_t<4>(e, L, in, resid, out, n);
 }
@@ -448,6 +473,7 @@ void apz_destroy(apz_engine* e) {
     for (auto ev : e->free_events) hipEventDestroy(ev);
     for (auto& l : e->convs) {
         if (l.wpk) hipFree(l.wpk);
+        if (l.upk) hipFree(l.upk);
         if (l.bias) hipFree(l.bias);
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
@@ -512,6 +538,7 @@ apz_engine* apz_create(const apz_config* cfg) {
     if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", err);
     e->ring = cfg->net_kind == APZ_NET_RESNET && cfg->height == 15 && cfg->width == 15 && cfg->n_filter == 128;
+    if (const char* tk = getenv("APZ_TRUNK_KERNEL")) e->wino = std::string(tk) != "ring";
     if (const char* tw = getenv("APZ_TRUNK_WAVES")) e->trunk_waves = (atoi(tw) == 8) ? 8 : 4;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
@@ -599,6 +626,33 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
         if (rc) return rc;
         rc = upload(&L.bias, bias);
         if (rc) return rc;
+        if (x4) {
+            // F(4x4,3x3) Winograd weights U[pos = 6i+k][co][ci] = (G g G^T)[i][k] of the BN-folded
+            // kernel g, in double, rounded once; packed [cot 8][chunk 8][pos 36][lane 64][4]
+            // (trunk15_wino.h).
+            static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6},
+                                           {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
+                                           {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            std::vector<float> up(apz::Wino15::UPK_FLOATS);
+            for (int co = 0; co < 128; co++)
+                for (int ci = 0; ci < 128; ci++) {
+                    double g[3][3], t[6][3];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) g[a][b] = (double)w[((size_t)co * 128 + ci) * 9 + a * 3 + b] * scale[co];
+                    for (int i = 0; i < 6; i++)
+                        for (int b = 0; b < 3; b++) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+                    const int cot = co >> 4, jj = co & 15;
+                    const int chunk = ci >> 4, s4 = (ci & 15) >> 2, qq = ci & 3;
+                    for (int i = 0; i < 6; i++)
+                        for (int k = 0; k < 6; k++) {
+                            const double u = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
+                            const size_t idx = ((((size_t)cot * 8 + chunk) * 36 + (i * 6 + k)) * 64 + (qq * 16 + jj)) * 4 + s4;
+                            up[idx] = (float)u;
+                        }
+                }
+            rc = upload(&L.upk, up);
+            if (rc) return rc;
+        }
     }
     // heads: two 1x1 conv_act (fix_gamma default) folded into one [6][C] matrix
     {
