@@ -18,6 +18,7 @@
 #include "heads.h"
 #include "trunk15_ring.h"
 #include "trunk15_wino.h"
+#include "trunk15_wino2.h"
 #include "sampler.h"
 #include "conv_train.h"
 
@@ -53,6 +54,7 @@ struct ConvLayer {
     bool residual;          // add the block input before ReLU
     float* wpk = nullptr;
     float* upk = nullptr;   // trunk15_wino_kernel: transformed weights G g G^T in MFMA fragment order
+    float* upk2 = nullptr;  // trunk15_wino2_kernel: the same values, [cot][pass][c4][lane][20]
     float* bias = nullptr;
 };
 
@@ -103,7 +105,8 @@ struct apz_engine {
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     bool wgrad_attr_set[2] = {false, false};
-    bool wino = true;       // trunk layers through trunk15_wino_kernel (APZ_TRUNK_KERNEL=ring: the direct kernel)
+    int trunk_kernel = 2;   // 0: trunk15_ring_kernel (direct), 1: trunk15_wino_kernel, 2: trunk15_wino2_kernel
+                            // (APZ_TRUNK_KERNEL=ring|wino|wino2)
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
     // profiling
     bool profiling = false;
@@ -315,8 +318,30 @@ int launch_trunk_wino(apz_engine* e, const ConvLayer& L, const float* in, const 
     return APZ_OK;
 }
 
+int launch_trunk_wino2(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Wino2;
+    bool& configured = e->lds_attr_set[5];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        configured = true;
+    }
+    const int grid = std::min((n + 1) / 2, e->num_cu);   // one persistent workgroup per CU, a pair of boards at a time
+    if (resid)
+        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
+                           L.bias, resid, out, n);
+    else
+        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
+                           L.bias, resid, out, n);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    if (e->wino && L.upk) return launch_trunk_wino(e, L, in, resid, out, n);
+    if (e->trunk_kernel == 2 && L.upk2) return launch_trunk_wino2(e, L, in, resid, out, n);
+    if (e->trunk_kernel == 1 && L.upk) return launch_trunk_wino(e, L, in, resid, out, n);
     if (e->trunk_waves == 8) return launch_trunk_ring_t<8>(e, L, in, resid, out, n);
     return launch_trunk_ring_t<4>(e, L, in, resid, out, n);
 }
@@ -474,6 +499,7 @@ void apz_destroy(apz_engine* e) {
     for (auto& l : e->convs) {
         if (l.wpk) hipFree(l.wpk);
         if (l.upk) hipFree(l.upk);
+        if (l.upk2) hipFree(l.upk2);
         if (l.bias) hipFree(l.bias);
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
@@ -538,7 +564,8 @@ apz_engine* apz_create(const apz_config* cfg) {
     if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", err);
     e->ring = cfg->net_kind == APZ_NET_RESNET && cfg->height == 15 && cfg->width == 15 && cfg->n_filter == 128;
-    if (const char* tk = getenv("APZ_TRUNK_KERNEL")) e->wino = std::string(tk) != "ring";
+    if (const char* tk = getenv("APZ_TRUNK_KERNEL"))
+        e->trunk_kernel = std::string(tk) == "ring" ? 0 : std::string(tk) == "wino" ? 1 : 2;
     if (const char* tw = getenv("APZ_TRUNK_WAVES")) e->trunk_waves = (atoi(tw) == 8) ? 8 : 4;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
@@ -633,7 +660,7 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
             static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6},
                                            {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
                                            {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-            std::vector<float> up(apz::Wino15::UPK_FLOATS);
+            std::vector<float> up(apz::Wino15::UPK_FLOATS), up2(apz::Wino2::UPK_FLOATS, 0.f);
             for (int co = 0; co < 128; co++)
                 for (int ci = 0; ci < 128; ci++) {
                     double g[3][3], t[6][3];
@@ -648,9 +675,13 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
                             const double u = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
                             const size_t idx = ((((size_t)cot * 8 + chunk) * 36 + (i * 6 + k)) * 64 + (qq * 16 + jj)) * 4 + s4;
                             up[idx] = (float)u;
+                            const int pass = i / 3, c4 = ci >> 2;
+                            up2[((((size_t)cot * 2 + pass) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * pass) * 6 + k] = (float)u;
                         }
                 }
             rc = upload(&L.upk, up);
+            if (rc) return rc;
+            rc = upload(&L.upk2, up2);
             if (rc) return rc;
         }
     }
