@@ -249,6 +249,9 @@ def main():
 
     games_per_s = playouts / N_PLAYOUT / mean_plies / dt
     batch = G // args.pipeline
+    # which trunk kernel ran (apz_engine.hip reads the same variable; default = the Winograd pair kernel)
+    tk = os.environ.get("APZ_TRUNK_KERNEL", "wino2")
+    tk = tk if tk in ("ring", "wino") else "wino2"
     # HBM traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
     # (cannot be collected from inside the process), committed under profiles/
     traffic = None
@@ -256,10 +259,17 @@ def main():
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("boards_per_launch") == batch:
+        if tj.get("boards_per_launch") == batch and tj.get("kernel", "ring") == tk:
             traffic = tj["traffic_bytes_per_launch"]["mean"]
     trunk_avg_ms = trunk_ms / max(trunk_cnt, 1)
     achieved_tf = trunk_flops(batch) / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
+    kernel_name = {"ring": "trunk15_ring_kernel<RESID,4> (direct 3x3 convolution on fp32 MFMA)",
+                   "wino": "trunk15_wino_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, one board per workgroup)",
+                   "wino2": "trunk15_wino2_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, two boards per workgroup)"}[tk]
+    # MFMA flops the kernel really issues: direct = the algorithmic count on 16-wide rows; Winograd =
+    # 36 positions x 8 channel tiles x 32 k-steps of v_mfma_f32_16x16x4_f32 (2048 flop) per board
+    executed = trunk_flops(batch) * 16.0 / 15.0 if tk == "ring" else batch * 9216 * 2048.0
+    executed_tf = executed / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
     line = {
         "metric": "self-play games/sec (15x15, n_playout=400)", "value": games_per_s, "unit": "games/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -271,9 +281,13 @@ def main():
         "leaf_evals_per_s": leafs / dt,
         "playouts_per_s": playouts / dt,
         "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
-        "roofline": {"kernel": "trunk15_ring_kernel<RESID,4> (trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward)",
+        "roofline": {"kernel": kernel_name + ": trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward",
                      "bound": "mfma", "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": (achieved_tf / FP32_MATRIX_PEAK_TF) if achieved_tf else None, "traffic": traffic,
+                     "frac": (achieved_tf / FP32_MATRIX_PEAK_TF) if achieved_tf else None,
+                     "achieved_basis": "algorithmic flops of the direct 3x3 convolution (2*9*128*128*225 per board) / launch time",
+                     "executed_mfma": {"tflops": executed_tf, "frac": (executed_tf / FP32_MATRIX_PEAK_TF) if executed_tf else None,
+                                       "flops_per_launch": executed},
+                     "traffic": traffic,
                      "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_trunk_traffic.json)",
                      "us_per_launch": trunk_avg_ms * 1e3, "launches": trunk_cnt,
                      "flops_per_launch": trunk_flops(batch), "boards_per_launch": batch},
