@@ -324,6 +324,11 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
                 v[3] = (q == 3) ? 0.f : fmaxf(v[3] + bv[ct], 0.f);
                 *reinterpret_cast<f32x4*>(st + j * OST + t * 16 + q * 4) = v;
             }
+            // lanes exchange data through the wave-private staging area: keep the compiler from moving a
+            // lane's reads above its own (different-address) writes, and the next tile's writes above these reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float* dst = out + ((size_t)b * T::C + (wave * 2 + ct) * 16) * T::GPLANE + lane * 4;
             if (lane < 60) {
 #pragma unroll
@@ -331,6 +336,9 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
                     __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(st + c * OST + lane * 4),
                                                 reinterpret_cast<f32x4*>(dst + c * T::GPLANE));
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }

@@ -49,7 +49,9 @@ struct Wino2 {
     static constexpr int RAW_FLOATS = RFRONT + 2 * CK * RPS;          // 5464
     static constexpr int VTS = 28;                     // floats per (board, channel, tile): 3 rows x 8, + 4 (bank spread)
     static constexpr int V_FLOATS = 2 * CK * 16 * VTS;                // 7168
-    static constexpr int LDS_FLOATS = 2 * RAW_FLOATS + 2 * V_FLOATS;  // 25264 floats = 98.7 KiB
+    static constexpr int SROW = 20, SPLANE = 16 * SROW;               // epilogue staging: 16 rows x 20 floats per plane
+    static constexpr int STAGE_FLOATS = 8 * 4 * SPLANE;               // 8 waves x 4 planes (10240 floats = 40 KiB)
+    static constexpr int LDS_FLOATS = 2 * RAW_FLOATS + 2 * V_FLOATS + STAGE_FLOATS;   // 35504 floats = 138.7 KiB
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int UROW = 20;                    // floats per lane and k-step in upk
     static constexpr size_t UPK_FLOATS = (size_t)8 * 2 * 32 * 64 * UROW;   // per layer (2.6 MB)
@@ -102,15 +104,40 @@ __device__ __forceinline__ void wino2_at6(const float m0, const float m1, const 
 #define APZ_WINO2_GSH 2
 #endif
 
+// Lanes of ONE wave exchange data through LDS (write in one layout, read in another).  The LDS executes a
+// wave's instructions in order, so no s_barrier is needed -- but the compiler reasons per thread and may move
+// a lane's read above its own (provably different-address) write.  This pins the order for the compiler.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool RESID>
 __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restrict__ in, const float* __restrict__ upk,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out,
                                                             int n) {
     using T = Wino2;
+#ifdef APZ_WINO_STAMPS
+    // cycle accounting per wave (tools/wino_ablate.hip): phases 0 prologue, 1 MFMA block + barrier wait,
+    // 2 staging, 3 transform, 4 (unused), 5 epilogue pass 0, 6 epilogue pass 1, 7 total
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_readcyclecounter();
+    const unsigned long long st_t0 = st_t;
+#define APZ_STAMP(ph)                                            \
+    {                                                            \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        st_acc[ph] += now_ - st_t;                               \
+        st_t = now_;                                             \
+    }
+#else
+#define APZ_STAMP(ph)
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* rawb = lds;                          // [2][RAW_FLOATS]
     float* vb = lds + 2 * T::RAW_FLOATS;        // [2][V_FLOATS]
+    float* stg = lds + 2 * T::RAW_FLOATS + 2 * T::V_FLOATS;   // [8 waves][4 planes][16 rows x 20]: wave-private epilogue staging
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,6 +238,7 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
     __syncthreads();
     if (group == 1) transform(0, std::true_type{});
     raw_fetch(2);
+    APZ_STAMP(0)
 
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + wave * 16 + q * 4);
     const int ety = j >> 2, etx = j & 3;
@@ -232,10 +260,12 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
 #ifndef APZ_WINO_ABL_NOBAR
                 __syncthreads();                // V[g&1] complete, V[(g+1)&1] and raw[g&1] free, raw[(g+1)&1] visible
 #endif
+                APZ_STAMP(1)
 #ifndef APZ_WINO_ABL_NORAW
                 raw_store(g + 2);
                 raw_fetch(g + 3);
 #endif
+                APZ_STAMP(2)
 #ifndef APZ_WINO_ABL_NOT
                 if (group == (g & 1) && g + 1 < total_iters) {
                     if (c + 1 < T::NCHUNK)      // the next chunk belongs to this pass, the last one to the other
@@ -245,6 +275,7 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
                 }
 #endif
 
+                APZ_STAMP(3)
                 const float* vp = vb + (g & 1) * T::V_FLOATS + (q * 16 + j) * T::VTS;
                 // k-steps of the NEXT iteration, for the ring refill
                 const int gn = g + 1;
@@ -295,11 +326,18 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
             // with h_i = the k-direction transform of row i.  Eight items (board, r) of 4 rows x 16 B per lane.
             // No branches: the missing second board of an odd batch's last pair is computed from a copy of
             // the first and its stores are masked; rows beyond the board are loaded from row 14, never stored.
+            APZ_STAMP(1)
             const int bd1 = two ? bd0 + 1 : bd0;
-            const int rowc[4] = {4 * ety, 4 * ety + 1, 4 * ety + 2, (4 * ety + 3 < 15) ? 4 * ety + 3 : 14};
-            const bool row3_ok = 4 * ety + 3 < 15;
-            auto item_base = [&](int it) {      // float offset of (board, channel) plane + tile column
-                return ((size_t)((it >> 2) ? bd1 : bd0) * T::C + co0 + (it & 3)) * T::GPLANE + 4 * etx;
+            // Memory access of the epilogue goes through a wave-private LDS staging area so that every global
+            // load / store instruction moves one whole 960-byte plane (60 lanes x 16 B, contiguous): in the
+            // accumulator layout a wave-instruction would touch 16 scattered 64-byte pieces, which the
+            // address coalescer serialises (measured: 19 us of stores + 10..28 us of loads per board pair).
+            // An item (board, r) covers the four planes co = 16*wave + 4*q' + r, q' = 0..3.
+            float* sw = stg + wave * (4 * T::SPLANE);
+            const int s_own = q * T::SPLANE + (4 * ety) * T::SROW + 4 * etx;        // this lane's 4x4 patch (row a: + a*SROW)
+            const int s_lin = (lane >> 2) * T::SROW + (lane & 3) * 4;               // plane piece `lane` (row lane>>2, quarter lane&3)
+            auto plane_ptr = [&](const float* basep, int it, int qp) {               // piece `lane` of plane q' of item it
+                return basep + ((size_t)((it >> 2) ? bd1 : bd0) * T::C + wave * 16 + qp * 4 + (it & 3)) * T::GPLANE + lane * 4;
             };
             auto item_y = [&](int it, f32x4* y) {
                 const int b = it >> 2, r = it & 3;
@@ -325,47 +363,73 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
                     }
                 }
             };
-            auto item_store = [&](int it, f32x4* y) {
-                float* ob = out + item_base(it);
+            auto item_store = [&](int it, f32x4* y) {   // patch layout -> staging -> four contiguous plane stores
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
                     if (etx == 3) y[a][3] = 0.f;   // column 15 is the halo column of the rows16 layout
-                    if ((a < 3 || row3_ok) && (it < 4 || two)) *reinterpret_cast<f32x4*>(ob + rowc[a] * 16) = y[a];
+                    *reinterpret_cast<f32x4*>(sw + s_own + a * T::SROW) = y[a];   // (row 15 of tile row 3 lands in the pad row)
+                }
+                wave_lds_fence();
+                f32x4 pv[4];
+#pragma unroll
+                for (int qp = 0; qp < 4; qp++) pv[qp] = *reinterpret_cast<const f32x4*>(sw + qp * T::SPLANE + s_lin);
+                wave_lds_fence();
+#pragma unroll
+                for (int qp = 0; qp < 4; qp++) {
+                    const f32x4 v = pv[qp];
+#ifdef APZ_WINO_ABL_NOST
+                    if (v[0] == 123.456f)
+#else
+                    if (lane < 60 && (it < 4 || two))
+#endif
+                        *reinterpret_cast<f32x4*>(const_cast<float*>(plane_ptr(out, it, qp))) = v;
                 }
             };
-            // Rolling window of two items: the loads of item k+2 are in flight while item k is finished.
+            // Rolling window of two items: the plane loads of item k+2 are in flight while item k is finished.
             // Pass 0 adds bias (+ residual) to its partial outputs, pass 1 adds pass 0's result and applies ReLU,
-            // so each epilogue streams ONE tensor (32 window registers next to the 144 live accumulators).
+            // so each epilogue streams ONE tensor.
             {
                 const float* src = (pass == 0) ? resid : out;
                 const bool has_src = (pass == 1) || RESID;
-                f32x4 win[2][4];
+                constexpr int WIN = 2;
+                f32x4 win[WIN][4];               // as loaded: plane pieces (lane = piece); rearranged through staging on use
                 auto item_load = [&](int it) {
-                    const size_t base = item_base(it);
 #pragma unroll
-                    for (int a = 0; a < 4; a++) win[it & 1][a] = *reinterpret_cast<const f32x4*>(src + base + rowc[a] * 16);
+                    for (int qp = 0; qp < 4; qp++)
+                        win[it % WIN][qp] = (lane < 60) ? *reinterpret_cast<const f32x4*>(plane_ptr(src, it, qp))
+                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
                 };
                 if (has_src) {
-                    item_load(0);
-                    item_load(1);
+#pragma unroll
+                    for (int it = 0; it < WIN; it++) item_load(it);
                 }
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
                     f32x4 y[4];
                     item_y(it, y);
                     const float bvr = bv[it & 3];
+                    f32x4 w4[4];
+                    if (has_src) {               // plane pieces -> staging -> this lane's 4x4 patch
+#pragma unroll
+                        for (int qp = 0; qp < 4; qp++)
+                            if (lane < 60) *reinterpret_cast<f32x4*>(sw + qp * T::SPLANE + s_lin) = win[it % WIN][qp];
+                        wave_lds_fence();
+#pragma unroll
+                        for (int a = 0; a < 4; a++) w4[a] = *reinterpret_cast<const f32x4*>(sw + s_own + a * T::SROW);
+                        wave_lds_fence();
+                    }
 #pragma unroll
                     for (int a = 0; a < 4; a++) {
                         if (pass == 0) {
                             y[a] = y[a] + bvr;
-                            if (RESID) y[a] += win[it & 1][a];
+                            if (RESID) y[a] += w4[a];
                         } else {
-                            const f32x4 v = y[a] + win[it & 1][a];
+                            const f32x4 v = y[a] + w4[a];
 #pragma unroll
                             for (int e = 0; e < 4; e++) y[a][e] = fmaxf(v[e], 0.f);
                         }
                     }
-                    if (has_src && it + 2 < 8) item_load(it + 2);
+                    if (has_src && it + WIN < 8) item_load(it + WIN);
                     item_store(it, y);
                 }
             }
@@ -379,10 +443,18 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
                     for (int v = 0; v < 5; v++) ur[s][v] = ubase[(size_t)(kn + s) * 64 * 5 + v];
             }
 #endif
+            APZ_STAMP(5 + pass)
         };
         run_pass(std::integral_constant<int, 0>{});
         run_pass(std::integral_constant<int, 1>{});
     }
+#ifdef APZ_WINO_STAMPS
+    st_acc[7] = __builtin_readcyclecounter() - st_t0;
+    if (lane == 0 && blockIdx.x < 4) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias) + 256) + (blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 8; i++) dst[i] = st_acc[i];
+    }
+#endif
 }
 
 }  // namespace apz

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     const size_t act = (size_t)nmax * 128 * 240;
     float *in, *res, *out, *upk, *bias;
     CK(hipMalloc(&in, act * 4)); CK(hipMalloc(&res, act * 4)); CK(hipMalloc(&out, act * 4));
-    CK(hipMalloc(&upk, T::UPK_FLOATS * 4)); CK(hipMalloc(&bias, 128 * 4));
+    CK(hipMalloc(&upk, T::UPK_FLOATS * 4)); CK(hipMalloc(&bias, 128 * 4 + 512 + 4 * 8 * 8 * 8 + 1024));
     std::vector<float> h(act);
     srand(1);
     for (size_t i = 0; i < act; i++) h[i] = ((i & 15) == 15) ? 0.f : (rand() % 1000) * 1e-5f;
@@ -62,6 +62,23 @@ int main(int argc, char** argv) {
                    100.0 * (9216.0 * 32 / 4 / 2.25e3) / (us / boards_per_wg), 2.0 * n * 128 * 128 * 9 * 225 / us / 1e6);
         }
     }
+#ifdef APZ_WINO_STAMPS
+    {
+        // stamps of the last launch (n = 4096?) are overwritten per launch: rerun n = 512, resid = 1 once
+        const int n = 512, grid = 256;
+        hipLaunchKernelGGL((KERN<true>), dim3(grid), dim3(512), T::LDS_BYTES, 0, in, upk, bias, res, out, n);
+        CK(hipDeviceSynchronize());
+        unsigned long long hst[4 * 8 * 8];
+        CK(hipMemcpy(hst, (char*)bias + 1024, sizeof(hst), hipMemcpyDeviceToHost));
+        const char* names[8] = {"prologue", "barrier", "staging", "transform", "mfma", "epi0", "epi1", "total"};
+        for (int wg = 0; wg < 2; wg++)
+            for (int w = 0; w < 8; w++) {
+                printf("wg %d wave %d:", wg, w);
+                for (int i = 0; i < 8; i++) printf(" %s %.1f", names[i], hst[(wg * 8 + w) * 8 + i] / 100.0);   // 100 MHz -> us
+                printf("\n");
+            }
+    }
+#endif
     CK(hipGetLastError());
     return 0;
 }
