@@ -288,7 +288,7 @@ def main():
                      "executed_mfma": {"tflops": executed_tf, "frac": (executed_tf / FP32_MATRIX_PEAK_TF) if executed_tf else None,
                                        "flops_per_launch": executed},
                      "traffic": traffic,
-                     "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_trunk_traffic.json)",
+                     "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_trunk_traffic.json; direct-convolution minimum 158 MB, see there)",
                      "us_per_launch": trunk_avg_ms * 1e3, "launches": trunk_cnt,
                      "flops_per_launch": trunk_flops(batch), "boards_per_launch": batch},
     }
