@@ -219,12 +219,17 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
     // then V(0) transformed and raw(2) in registers.
     // weight stream of this wave: k-step (pass, c4) -> five f32x4 per lane; a ring of two k-steps
     // (= one iteration) ahead.  The stream wraps (pass 1 -> pass 0 of the next pair: same weights).
-    const f32x4* ubase = reinterpret_cast<const f32x4*>(upk) + ((size_t)wave * 2 * 32 * 64 + lane) * 5;
+    // uniform (SGPR) base + one 32-bit lane offset: `global_load ... v_off, s[base]`, no 64-bit VALU address math
+    const char* uwave = reinterpret_cast<const char*>(upk) + (size_t)wave * (2 * 32 * 64 * T::UROW * 4);
+    const unsigned ulane = lane * (T::UROW * 4);
+    auto uload = [&](int kstep, int v) {       // k-step = pass*32 + c4 (uniform), v = 16-byte piece 0..4
+        return *reinterpret_cast<const f32x4*>(uwave + (size_t)kstep * (64 * T::UROW * 4) + (ulane + v * 16));
+    };
     f32x4 ur[2][5];
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int v = 0; v < 5; v++) ur[s][v] = ubase[(size_t)s * 64 * 5 + v];
+        for (int v = 0; v < 5; v++) ur[s][v] = uload(s, v);
     {
         raw_fetch(0);
         const f32x4 r0 = rg[0], r1 = rg[1];
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
 #ifndef APZ_WINO_ABL_NOW
                     if (c + 1 < T::NCHUNK) {    // at the end of a pass the ring is reloaded after the epilogue (registers)
 #pragma unroll
-                        for (int v = 0; v < 5; v++) ur[s][v] = ubase[(size_t)(kn + s) * 64 * 5 + v];
+                        for (int v = 0; v < 5; v++) ur[s][v] = uload(kn + s, v);
                     }
 #endif
                 }
@@ -337,7 +342,9 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
             const int s_own = q * T::SPLANE + (4 * ety) * T::SROW + 4 * etx;        // this lane's 4x4 patch (row a: + a*SROW)
             const int s_lin = (lane >> 2) * T::SROW + (lane & 3) * 4;               // plane piece `lane` (row lane>>2, quarter lane&3)
             auto plane_ptr = [&](const float* basep, int it, int qp) {               // piece `lane` of plane q' of item it
-                return basep + ((size_t)((it >> 2) ? bd1 : bd0) * T::C + wave * 16 + qp * 4 + (it & 3)) * T::GPLANE + lane * 4;
+                const int pl = __builtin_amdgcn_readfirstlane(((it >> 2) ? bd1 : bd0) * T::C + wave * 16 + qp * 4 + (it & 3));
+                return reinterpret_cast<const float*>(reinterpret_cast<const char*>(basep) + (size_t)pl * (T::GPLANE * 4) +
+                                                      (unsigned)(lane * 16));
             };
             auto item_y = [&](int it, f32x4* y) {
                 const int b = it >> 2, r = it & 3;
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
 #pragma unroll
                 for (int s = 0; s < 2; s++)
 #pragma unroll
-                    for (int v = 0; v < 5; v++) ur[s][v] = ubase[(size_t)(kn + s) * 64 * 5 + v];
+                    for (int v = 0; v < 5; v++) ur[s][v] = uload(kn + s, v);
             }
 #endif
             APZ_STAMP(5 + pass)
