@@ -62,8 +62,9 @@ def build_hip(force=False):
         [os.path.join(INC, "alphapig_hip.h")]
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB
+    extra = os.environ.get("APZ_HIPCC_EXTRA", "").split()     # experiment switches (-DAPZ_...), never needed for a normal build
     _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-ffp-contract=off", "-Wall", "-Wno-unused-result", "-I" + INC, "-I" + CSRC] + srcs + ["-o", HIP_LIB])
+          "-ffp-contract=off", "-Wall", "-Wno-unused-result", "-I" + INC, "-I" + CSRC] + extra + srcs + ["-o", HIP_LIB])
     return HIP_LIB
 
 
