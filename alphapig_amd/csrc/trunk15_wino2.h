@@ -151,34 +151,26 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
     const int total_iters = np * T::ITERS;
     if (np == 0) return;                        // (launchers never oversubscribe; uniform, before any barrier)
 
-    // ---- staging roles: 2 boards x 8 planes x 60 pieces of 16 B = 960 pieces, thread -> pieces tid, tid + 512
-    // (threads 448..511 repeat their first piece).  Every thread issues exactly two loads and two LDS
+    // ---- staging roles: 2 boards x 8 planes x 60 pieces of 16 B, 32 threads per plane, two pieces each (four of
+    // them twice).  Every thread issues exactly two loads and two LDS
     // stores per iteration, unconditionally -- the compiler can then count vmcnt exactly and the
     // MFMA phase never waits for the (HBM-latency) staging loads that were issued after its weights.
-    int st_src[2], st_dst[2];                   // float offsets: within a (board, chunk) block of `in` / within a raw buffer
-    int st_b[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int idx = (tid + u * 512 < 960) ? tid + u * 512 : tid;
-        const int p16 = idx / 60, piece = idx - p16 * 60;
-        st_b[u] = p16 >> 3;
-        st_src[u] = (p16 & 7) * T::GPLANE + piece * 4;
-        st_dst[u] = T::RFRONT + p16 * T::RPS + (piece >> 2) * T::RROW + (piece & 3) * 4;
-    }
+    // thread -> plane tid>>5 (board = tid>>8, channel = (tid>>5)&7), pieces k = tid&31 and k+32 (k+32 >= 60: k again);
+    // everything below is a shift or an add of tid, so nothing has to stay in registers across the chunk loop
+    const int st_k = tid & 31, st_k2 = (st_k + 32 < 60) ? st_k + 32 : st_k;
     f32x4 rg[2];
     auto raw_fetch = [&](int g) {               // global -> registers (iteration g of this workgroup's stream, clamped)
         g = g < total_iters ? g : total_iters - 1;
-        const int bd0 = 2 * ((int)blockIdx.x + (g / T::ITERS) * (int)gridDim.x), c = g & (T::NCHUNK - 1);
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int bd = bd0 + st_b[u] < n ? bd0 + st_b[u] : n - 1;
-            rg[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)bd * T::C + c * T::CK) * T::GPLANE + st_src[u]);
-        }
+        const int bdp = 2 * ((int)blockIdx.x + (g / T::ITERS) * (int)gridDim.x) + (tid >> 8), c = g & (T::NCHUNK - 1);
+        const int bd = bdp < n ? bdp : n - 1;
+        const float* pl = in + ((size_t)bd * T::C + c * T::CK + ((tid >> 5) & 7)) * T::GPLANE;
+        rg[0] = *reinterpret_cast<const f32x4*>(pl + st_k * 4);
+        rg[1] = *reinterpret_cast<const f32x4*>(pl + st_k2 * 4);
     };
     auto raw_store = [&](int g) {               // registers -> raw LDS buffer g&1
-        float* dst = rawb + (g & 1) * T::RAW_FLOATS;
-#pragma unroll
-        for (int u = 0; u < 2; u++) *reinterpret_cast<f32x4*>(dst + st_dst[u]) = rg[u];
+        float* dst = rawb + (g & 1) * T::RAW_FLOATS + T::RFRONT + (tid >> 5) * T::RPS;
+        *reinterpret_cast<f32x4*>(dst + (st_k >> 2) * T::RROW + (st_k & 3) * 4) = rg[0];
+        *reinterpret_cast<f32x4*>(dst + (st_k2 >> 2) * T::RROW + (st_k2 & 3) * 4) = rg[1];
     };
     // ---- transform roles (256 threads of one wave group): unit = (board, channel, tile)
     const int unit = (APZ_WINO2_GSH == 2 ? (wave & 3) : (wave >> 1)) * 64 + lane;
@@ -332,6 +324,7 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
             // No branches: the missing second board of an odd batch's last pair is computed from a copy of
             // the first and its stores are masked; rows beyond the board are loaded from row 14, never stored.
             APZ_STAMP(1)
+            __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's loads out of the last chunk's MFMA block (register pressure)
             const int bd1 = two ? bd0 + 1 : bd0;
             // Memory access of the epilogue goes through a wave-private LDS staging area so that every global
             // load / store instruction moves one whole 960-byte plane (60 lanes x 16 B, contiguous): in the
