@@ -62,6 +62,32 @@ int main(int argc, char** argv) {
                    100.0 * (9216.0 * 32 / 4 / 2.25e3) / (us / boards_per_wg), 2.0 * n * 128 * 128 * 9 * 225 / us / 1e6);
         }
     }
+#ifdef APZ_HARNESS_TWO_STREAMS
+    {
+        // do two independent launch chains on two streams hide each other's inter-kernel gaps?
+        const int n = 512, grid = 256, iters = 40;
+        hipStream_t s1, s2;
+        CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+        CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        float *in2 = in + (size_t)2048 * 128 * 240, *out2 = out + (size_t)2048 * 128 * 240, *res2 = res + (size_t)2048 * 128 * 240;
+        for (int mode = 0; mode < 2; mode++) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(a, s1));
+            for (int i = 0; i < iters; i++) {
+                hipStream_t st = (mode == 1 && (i & 1)) ? s2 : s1;
+                const bool second = i & 1;
+                hipLaunchKernelGGL((KERN<true>), dim3(grid), dim3(512), T::LDS_BYTES, st, second ? in2 : in, upk, bias,
+                                   second ? res2 : res, second ? out2 : out, n);
+            }
+            CK(hipStreamSynchronize(s2));
+            CK(hipEventRecord(b, s1));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            printf("two-chain test, %s: %.1f us per launch\n", mode ? "two streams" : "one stream", ms * 1e3 / iters);
+        }
+    }
+#endif
 #ifdef APZ_WINO_STAMPS
     {
         // stamps of the last launch (n = 4096?) are overwritten per launch: rerun n = 512, resid = 1 once
