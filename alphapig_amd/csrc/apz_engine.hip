@@ -104,6 +104,8 @@ struct apz_engine {
     int32_t* smp_mv = nullptr;
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
+    float* wino_scratch[2] = {nullptr, nullptr};   // apz_wino_conv: rows16 input / output copies
+    size_t wino_scratch_boards = 0;
     bool wgrad_attr_set[2] = {false, false};
     int trunk_kernel = 2;   // 0: trunk15_ring_kernel (direct), 1: trunk15_wino_kernel, 2: trunk15_wino2_kernel
                             // (APZ_TRUNK_KERNEL=ring|wino|wino2)
@@ -503,7 +505,8 @@ void apz_destroy(apz_engine* e) {
         if (l.bias) hipFree(l.bias);
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
-                   e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256};
+                   e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
+                   e->wino_scratch[0], e->wino_scratch[1]};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -964,6 +967,66 @@ int apz_conv3x3_fwd(apz_engine* e, const void* x_dev, const void* wpk_dev, const
     L.bias = nullptr;
     if (rc == APZ_E_UNSUPPORTED) return fail(rc, "conv3x3_fwd: unsupported board size");
     return rc;
+}
+
+int64_t apz_wino_packed_size(void) { return (int64_t)apz::Wino2::UPK_FLOATS; }
+
+int apz_wino_pack(apz_engine* e, const void* w_dev, int transpose_flip, void* upk_dev, void* stream) {
+    if (!e || !w_dev || !upk_dev) return fail(APZ_E_ARG, "bad argument");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    hipLaunchKernelGGL(apz::pack_wino2_kernel, dim3(8 * 2 * 32 * 64 / 256), dim3(256), 0, e->stream, (const float*)w_dev,
+                       (float*)upk_dev, transpose_flip);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, void* y_dev, int n, int relu,
+                  void* stream) {
+    if (!e || !x_dev || !upk_dev || !y_dev || n < 1) return fail(APZ_E_ARG, "bad argument");
+    if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wino_conv: 15x15 boards only");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (!e->zeros256) {
+        HIP_TRY(hipMalloc((void**)&e->zeros256, 256 * sizeof(float)));
+        HIP_TRY(hipMemset(e->zeros256, 0, 256 * sizeof(float)));
+    }
+    StreamScope sc(e, stream);
+    if ((size_t)n > e->wino_scratch_boards) {   // grow the rows16 copies (previous users are ordered on their stream)
+        HIP_TRY(hipDeviceSynchronize());
+        for (int i = 0; i < 2; i++) {
+            if (e->wino_scratch[i]) HIP_TRY(hipFree(e->wino_scratch[i]));
+            e->wino_scratch[i] = nullptr;
+            HIP_TRY(hipMalloc((void**)&e->wino_scratch[i], (size_t)n * 128 * 240 * sizeof(float)));
+        }
+        e->wino_scratch_boards = n;
+    }
+    using T = apz::Wino2;
+    bool& configured = e->lds_attr_set[7];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<false, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        configured = true;
+    }
+    const long planes = (long)n * 128;
+    const int cgrid = (int)std::min<long>((planes * 240 + 255) / 256, 16384);
+    hipLaunchKernelGGL(apz::rows16_from_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, (const float*)x_dev,
+                       e->wino_scratch[0], planes);
+    const float* b = bias_dev ? (const float*)bias_dev : e->zeros256;
+    const int grid = std::min((n + 1) / 2, e->num_cu);
+    if (relu)
+        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream,
+                           e->wino_scratch[0], (const float*)upk_dev, b, nullptr, e->wino_scratch[1], n);
+    else
+        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream,
+                           e->wino_scratch[0], (const float*)upk_dev, b, nullptr, e->wino_scratch[1], n);
+    hipLaunchKernelGGL(apz::rows16_to_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, e->wino_scratch[1], (float*)y_dev,
+                       planes);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
 }
 
 int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, int cin, int cout,

@@ -52,6 +52,70 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// w [128][128][3][3] -> the transformed weights of trunk15_wino2_kernel, U = G g G^T in fp32:
+// [cot 8][pass 2][c4 32][lane 64][20] (trunk15_wino2.h).  One thread per (cot, pass, c4, lane): 18 values,
+// 80 contiguous bytes.  transpose_flip: the weights of the data-gradient convolution (see above).
+__global__ void pack_wino2_kernel(const float* __restrict__ w, float* __restrict__ upk, int transpose_flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 8 * 2 * 32 * 64) return;
+    const int lane = i & 63, c4 = (i >> 6) & 31, pass = (i >> 11) & 1, cot = i >> 12;
+    const int co = cot * 16 + (lane & 15), ci = c4 * 4 + (lane >> 4);
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+            g[a][b] = transpose_flip ? w[((size_t)ci * 128 + co) * 9 + (2 - a) * 3 + (2 - b)] : w[((size_t)co * 128 + ci) * 9 + a * 3 + b];
+    auto G6 = [](float g0, float g1, float g2, float* u) {
+        const float e = g0 + g2, f = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), h = g1 * (1.f / 12.f);
+        u[0] = g0 * 0.25f;
+        u[1] = (e + g1) * (-1.f / 6.f);
+        u[2] = (e - g1) * (-1.f / 6.f);
+        u[3] = f + h;
+        u[4] = f - h;
+        u[5] = g2;
+    };
+    float t[3][6];                               // t[b][i] = sum_a G[i][a] g[a][b]
+#pragma unroll
+    for (int b = 0; b < 3; b++) G6(g[0][b], g[1][b], g[2][b], t[b]);
+    float out[20];
+#pragma unroll
+    for (int ii = 0; ii < 3; ii++) {
+        const int r = 3 * pass + ii;
+        float u[6];
+        // (pass is a runtime value: pick the row without a dynamic register index)
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++)
+            if (rr == r) t0 = t[0][rr], t1 = t[1][rr], t2 = t[2][rr];
+        G6(t0, t1, t2, u);
+#pragma unroll
+        for (int k = 0; k < 6; k++) out[ii * 6 + k] = u[k];
+    }
+    out[18] = out[19] = 0.f;
+    f32x4* dst = reinterpret_cast<f32x4*>(upk + (size_t)i * 20);
+#pragma unroll
+    for (int v = 0; v < 5; v++) dst[v] = f32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+}
+
+// dense [planes][15][15] <-> rows16 [planes][15][16] (pad column written as zero)
+__global__ void rows16_from_dense_kernel(const float* __restrict__ x, float* __restrict__ y, long planes) {
+    const long total = planes * 240;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pl = i / 240;
+        const int rem = (int)(i - pl * 240), row = rem >> 4, col = rem & 15;
+        y[i] = col < 15 ? x[pl * 225 + row * 15 + col] : 0.f;
+    }
+}
+__global__ void rows16_to_dense_kernel(const float* __restrict__ x, float* __restrict__ y, long planes) {
+    const long total = planes * 225;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pl = i / 225;
+        const int rem = (int)(i - pl * 225), row = rem / 15, col = rem - row * 15;
+        y[i] = x[pl * 240 + row * 16 + col];
+    }
+}
+
 template <int H, int W>
 struct WgradGeo {
     static constexpr int HW = H * W;

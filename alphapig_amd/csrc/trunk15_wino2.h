@@ -113,7 +113,8 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool RESID>
+// RELU = false: the plain convolution + bias (training graph: forward before BatchNorm, data gradient)
+template <bool RESID, bool RELU = true>
 __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restrict__ in, const float* __restrict__ upk,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out,
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(512) void trunk15_wino2_kernel(const float* __restr
                         } else {
                             const f32x4 v = y[a] + w4[a];
 #pragma unroll
-                            for (int e = 0; e < 4; e++) y[a][e] = fmaxf(v[e], 0.f);
+                            for (int e = 0; e < 4; e++) y[a][e] = RELU ? fmaxf(v[e], 0.f) : v[e];
                         }
                     }
                     if (has_src && it + WIN < 8) item_load(it + WIN);

@@ -34,6 +34,17 @@ def supported(x, weight):
             co in (64, 128, 256) and tuple(x.shape[2:]) in ((15, 15), (8, 8)))
 
 
+def _wino(x, weight):
+    """The trunk shape (128 -> 128 at 15x15) runs on the fused Winograd pair kernel of the self-play path once
+    the batch fills the chip (one workgroup per pair of boards: >= 192 boards; measured 24.2 vs 31.0 ms per
+    training step at batch 512, 12.3 vs 11.8 ms at batch 128).  APZ_TRAIN_CONV=direct / wino forces a path."""
+    import os
+    if tuple(weight.shape) != (128, 128, 3, 3) or tuple(x.shape[2:]) != (15, 15):
+        return False
+    mode = os.environ.get("APZ_TRAIN_CONV", "auto")
+    return mode == "wino" or (mode != "direct" and x.shape[0] >= 192)
+
+
 def _ck(L, rc):
     if rc < 0:
         raise RuntimeError("%s (code %d)" % (L.apz_last_error().decode(), rc))
@@ -52,11 +63,16 @@ def _function():
             co = weight.shape[0]
             hnd = _engine(h, w, x.device.index or 0)
             stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            wpk = torch.empty(L.apz_conv3x3_packed_size(ci, co), dtype=torch.float32, device=x.device)
-            _ck(L, L.apz_conv3x3_pack(hnd, weight.data_ptr(), ci, co, 0, wpk.data_ptr(), stream))
             y = torch.empty((n, co, h, w), dtype=torch.float32, device=x.device)
             bptr = bias.contiguous().data_ptr() if bias is not None else None
-            _ck(L, L.apz_conv3x3_fwd(hnd, x.data_ptr(), wpk.data_ptr(), bptr, y.data_ptr(), n, ci, co, 0, stream))
+            if _wino(x, weight):
+                upk = torch.empty(L.apz_wino_packed_size(), dtype=torch.float32, device=x.device)
+                _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), 0, upk.data_ptr(), stream))
+                _ck(L, L.apz_wino_conv(hnd, x.data_ptr(), upk.data_ptr(), bptr, y.data_ptr(), n, 0, stream))
+            else:
+                wpk = torch.empty(L.apz_conv3x3_packed_size(ci, co), dtype=torch.float32, device=x.device)
+                _ck(L, L.apz_conv3x3_pack(hnd, weight.data_ptr(), ci, co, 0, wpk.data_ptr(), stream))
+                _ck(L, L.apz_conv3x3_fwd(hnd, x.data_ptr(), wpk.data_ptr(), bptr, y.data_ptr(), n, ci, co, 0, stream))
             ctx.save_for_backward(x, weight)
             ctx.has_bias = bias is not None
             return y
@@ -72,7 +88,12 @@ def _function():
             stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
             dx = dw = db = None
             if ctx.needs_input_grad[0]:
-                if ci in (64, 128, 256):
+                if _wino(x, weight):
+                    upk = torch.empty(L.apz_wino_packed_size(), dtype=torch.float32, device=x.device)
+                    _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), 1, upk.data_ptr(), stream))
+                    dx = torch.empty_like(x)
+                    _ck(L, L.apz_wino_conv(hnd, dy.data_ptr(), upk.data_ptr(), None, dx.data_ptr(), n, 0, stream))
+                elif ci in (64, 128, 256):
                     wpk = torch.empty(L.apz_conv3x3_packed_size(co, ci), dtype=torch.float32, device=x.device)
                     _ck(L, L.apz_conv3x3_pack(hnd, weight.data_ptr(), ci, co, 1, wpk.data_ptr(), stream))
                     dx = torch.empty_like(x)

@@ -134,6 +134,16 @@ int apz_conv3x3_fwd(apz_engine *e, const void *x_dev, const void *wpk_dev, const
                     void *y_dev, int n, int cin_p, int cout_p, int relu, void *stream);
 int apz_conv3x3_wgrad(apz_engine *e, const void *x_dev, const void *dy_dev, void *dw_dev, int n,
                       int cin, int cout, void *stream);
+/* The same forward / data-gradient convolution for the trunk shape (128 -> 128 channels, 15x15) on the
+ * fused Winograd F(4x4,3x3) kernel of the self-play path (csrc/trunk15_wino2.h):
+ *   apz_wino_pack   w_dev [128][128][3][3] -> upk_dev (apz_wino_packed_size floats), U = G g G^T in fp32
+ *                   on the device; transpose_flip as in apz_conv3x3_pack
+ *   apz_wino_conv   y = conv(x, upk) + bias_dev (NULL: none) (ReLU if relu), x / y dense [n][128][15][15]
+ *                   (copied to / from the kernel's padded-row layout in engine-owned scratch) */
+int64_t apz_wino_packed_size(void);
+int apz_wino_pack(apz_engine *e, const void *w_dev, int transpose_flip, void *upk_dev, void *stream);
+int apz_wino_conv(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev,
+                  void *y_dev, int n, int relu, void *stream);
 
 int apz_sync(apz_engine *e);
 void *apz_stream(apz_engine *e);

@@ -39,6 +39,31 @@ def test_conv3x3_fwd_dgrad_wgrad(n, ci, co, hw):
         assert float((xc.grad.cpu().double() - x64.grad).abs().max()) < tol(x64.grad)
 
 
+@pytest.mark.parametrize("n", [1, 6, 131])
+def test_trunk_shape_winograd_and_direct_paths_agree(n, monkeypatch):
+    """128 -> 128 at 15x15 runs on the self-play path's fused Winograd kernel from 192 boards on
+    (APZ_TRAIN_CONV=wino / direct force a path): both against torch float64, forward and data gradient."""
+    from alphapig_amd import hipconv
+    g = torch.Generator().manual_seed(900 + n)
+    x = torch.randn(n, 128, 15, 15, generator=g)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34.0).float()
+    b = torch.randn(128, generator=g)
+    dy = torch.randn(n, 128, 15, 15, generator=g)
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, b64, padding=1)
+    y64.backward(dy.double())
+    for mode in ("wino", "direct"):
+        monkeypatch.setenv("APZ_TRAIN_CONV", mode)
+        xc, wc, bc = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        y = hipconv.conv3x3(xc, wc, bc)
+        y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        tol = lambda ref: 2e-5 * float(ref.detach().abs().max()) + 1e-6
+        assert float((y.detach().cpu().double() - y64.detach()).abs().max()) < tol(y64), mode
+        assert float((xc.grad.cpu().double() - x64.grad).abs().max()) < tol(x64.grad), mode
+        assert float((wc.grad.cpu().double() - w64.grad).abs().max()) < 5 * tol(w64.grad), mode
+
+
 def test_trainer_with_hip_convs_matches_torch_convs():
     """One optimiser step of the interim trainer with the 3x3 convolutions on the HIP kernels ==
     the same step on torch's convolutions (same dropout stream)."""
@@ -56,5 +81,10 @@ def test_trainer_with_hip_convs_matches_torch_convs():
         losses = [tr.train_step(states, pis, zs, 1e-3)[0] for _ in range(3)]
         out[backend] = (losses, tr.get_params())
     np.testing.assert_allclose(out["hip"][0], out["torch"][0], rtol=2e-4)
+    # Adam's first updates are ~lr * sign(g): where |g| is at the rounding-noise level the two convolution
+    # implementations (fp32 Winograd / direct vs MIOpen) may step in opposite directions, so a few elements
+    # per mille differ by up to 2 * lr * steps; everything else agrees to 2e-4.
     for k in ("convA1_weight", "convB2_weight", "res_conv1_weight", "fc_3_1_1_weight", "bnA1_moving_var"):
-        np.testing.assert_allclose(out["hip"][1][k], out["torch"][1][k], rtol=0, atol=2e-4)
+        d = np.abs(out["hip"][1][k] - out["torch"][1][k])
+        assert float((d > 2e-4).mean()) < 5e-3, k
+        assert float(d.max()) < 2 * 1e-3 * 3 + 2e-4, k

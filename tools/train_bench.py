@@ -27,8 +27,11 @@ def main():
         states = (rs.rand(B, 9, 15, 15) > 0.7).astype(np.float32)
         pis = rs.dirichlet(np.ones(225), size=B).astype(np.float32)
         zs = rs.choice([-1.0, 1.0], size=B).astype(np.float32)
-        for backend in ("torch", "hip"):
-            tr = TorchTrainer(prm, "resnet", n_blocks=10, batch_size=B, device="cuda", conv_backend=backend)
+        for backend in ("torch", "hip-direct", "hip-wino", "hip"):
+            # "hip": the default choice (Winograd pair kernel for forward / dgrad of the trunk shape from 192 boards)
+            os.environ["APZ_TRAIN_CONV"] = {"hip-direct": "direct", "hip-wino": "wino"}.get(backend, "auto")
+            tr = TorchTrainer(prm, "resnet", n_blocks=10, batch_size=B, device="cuda",
+                              conv_backend="torch" if backend == "torch" else "hip")
             for _ in range(3):
                 tr.train_step(states, pis, zs, 1e-3)
             torch.cuda.synchronize()
@@ -39,7 +42,7 @@ def main():
             ms = 1e3 * (time.perf_counter() - t) / args.steps
             flops = 3 * 2.0 * B * (9 * 128 + 20 * 128 * 128) * 9 * 225       # fwd + dgrad + wgrad of the 3x3 convs
             out["B%d_%s" % (B, backend)] = {"ms_per_step": ms, "conv_tflops_equiv": flops / ms / 1e9}
-            print("batch %4d  convs=%-5s  %.2f ms/step   (3x3-conv work %.1f TFLOP/s equivalent)" %
+            print("batch %4d  convs=%-10s  %.2f ms/step   (3x3-conv work %.1f TFLOP/s equivalent)" %
                   (B, backend, ms, flops / ms / 1e9), flush=True)
     print(json.dumps(out))
 
