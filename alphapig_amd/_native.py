@@ -5,6 +5,12 @@ There is NO fallback: if a library is missing the import error says how to build
 import ctypes as C
 import os
 
+# The tree pool's OpenMP threads must SLEEP between parallel regions: a GPU box grants a CPU quota (cgroup
+# cpu.max, e.g. 16 cores), and spinning workers burn it -- the kernel then throttles the whole process for the
+# rest of the 100 ms period (measured: a 10 ms stall every ~30-50 self-play steps, ~5 % of the throughput).
+# libgomp reads the variable when it initialises, so it is set here, before any OpenMP library is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))

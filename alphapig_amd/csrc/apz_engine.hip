@@ -61,6 +61,7 @@ struct ConvLayer {
 struct Pending {
     int cls;
     hipEvent_t a, b;
+    int launches;   // kernel launches bracketed by the pair
 };
 
 }  // namespace
@@ -209,13 +210,18 @@ hipEvent_t get_event(apz_engine* e) {
         return ev;
     }
     hipEvent_t ev;
-    hipEventCreate(&ev);
+    // timing events only order work on this one device: no system-scope fence (cache write-back) when they fire
+    if (hipEventCreateWithFlags(&ev, hipEventDisableSystemFence) != hipSuccess) hipEventCreate(&ev);
     return ev;
 }
 
+// Brackets one or MORE consecutive launches of one kernel class with a single event pair: an event between
+// two kernels costs a barrier packet + cache maintenance (~0.1 ms each under load), so the 20 trunk launches of
+// a sampled forward share one pair and their average duration is elapsed / launches.
 struct Timed {
     apz_engine* e;
     int cls;
+    int launches = 1;
     hipEvent_t a = nullptr, b = nullptr;
     Timed(apz_engine* e_, int cls_) : e(e_), cls(cls_) {
         if (e->profiling && e->prof_now) {
@@ -227,7 +233,7 @@ struct Timed {
     ~Timed() {
         if (a) {
             hipEventRecord(b, e->stream);
-            e->pending.push_back({cls, a, b});
+            e->pending.push_back({cls, a, b, launches});
         }
     }
 };
@@ -237,7 +243,7 @@ void resolve_pending(apz_engine* e) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             e->k_ms[p.cls] += ms;
-            e->k_cnt[p.cls] += 1;
+            e->k_cnt[p.cls] += p.launches;
         }
         e->free_events.push_back(p.a);
         e->free_events.push_back(p.b);
@@ -389,29 +395,41 @@ int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** resul
     float *x = e->act[0], *t = e->act[1], *y = e->act[2];
     const float* cur = planes;
     const int nl = (int)e->convs.size();
-    for (int li = 0; li <= upto && li < nl; li++) {
-        const ConvLayer& L = e->convs[li];
-        Timed tm(e, li == 0 ? APZ_K_STEM : APZ_K_TRUNK);
+    const int last = std::min(upto, nl - 1);
+    {
+        Timed tm(e, APZ_K_STEM);
         if (e->cfg.net_kind == APZ_NET_RESNET) {
-            if (li == 0) {
-                int rc = launch_conv(e, L, cur, nullptr, x, n);
-                if (rc) return rc;
-                cur = x;
-            } else if (!L.residual) {   // convA: x -> t
-                int rc = launch_conv(e, L, x, nullptr, t, n);
-                if (rc) return rc;
-                cur = t;
-            } else {                    // convB: t (+x) -> y ; then y becomes the block output
-                int rc = launch_conv(e, L, t, x, y, n);
-                if (rc) return rc;
-                std::swap(x, y);
-                cur = x;
-            }
-        } else {
-            float* dst = (cur == x) ? t : x;
-            int rc = launch_conv(e, L, cur, nullptr, dst, n);
+            int rc = launch_conv(e, e->convs[0], cur, nullptr, x, n);
             if (rc) return rc;
-            cur = dst;
+            cur = x;
+        } else {
+            int rc = launch_conv(e, e->convs[0], cur, nullptr, x, n);
+            if (rc) return rc;
+            cur = x;
+        }
+    }
+    if (last >= 1) {
+        Timed tm(e, APZ_K_TRUNK);       // all trunk launches of this forward under one event pair
+        tm.launches = last;
+        for (int li = 1; li <= last; li++) {
+            const ConvLayer& L = e->convs[li];
+            if (e->cfg.net_kind == APZ_NET_RESNET) {
+                if (!L.residual) {          // convA: x -> t
+                    int rc = launch_conv(e, L, x, nullptr, t, n);
+                    if (rc) return rc;
+                    cur = t;
+                } else {                    // convB: t (+x) -> y ; then y becomes the block output
+                    int rc = launch_conv(e, L, t, x, y, n);
+                    if (rc) return rc;
+                    std::swap(x, y);
+                    cur = x;
+                }
+            } else {
+                float* dst = (cur == x) ? t : x;
+                int rc = launch_conv(e, L, cur, nullptr, dst, n);
+                if (rc) return rc;
+                cur = dst;
+            }
         }
     }
     *result = const_cast<float*>(cur);

@@ -27,7 +27,9 @@ import os
 import sys
 import time
 
-import numpy as np
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before numpy / torch load an OpenMP runtime (see alphapig_amd/_native.py)
+
+import numpy as np  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
