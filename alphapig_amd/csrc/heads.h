@@ -94,22 +94,46 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
     for (int i = 0; i < TPW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* arow = sm + j * ldf + q;
     // K loop, 8 k-steps per trip so that the 8 x TPW weight-fragment loads (L2) of a trip are in
-    // flight together instead of one dependent L2 round trip per MFMA (KS = H*W: 225 = 28*8 + 1)
+    // flight together instead of one dependent L2 round trip per MFMA (KS = H*W: 225 = 28*8 + 1);
+    // the NEXT trip's fragments are loaded before this trip's MFMAs issue (register double buffer),
+    // so the L2 latency of a trip hides behind the 8 x TPW MFMAs of the previous one.
     int s = 0;
-    for (; s + 8 <= KS; s += 8) {
-        float a[8], bw[TPW][8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + u)];
+    float bw[2][TPW][8];
+    auto load_trip = [&](int s0, int buf) {
 #pragma unroll
         for (int i = 0; i < TPW; i++) {
             const int nt = min(wave + 4 * i, ntile - 1);   // clamp: surplus tiles recompute the last one
 #pragma unroll
-            for (int u = 0; u < 8; u++) bw[i][u] = wfc_pk[((size_t)nt * KS + s + u) * 64 + lane];
+            for (int u = 0; u < 8; u++) bw[buf][i][u] = wfc_pk[((size_t)nt * KS + s0 + u) * 64 + lane];
         }
+    };
+    if (KS >= 8) load_trip(0, 0);
+    for (; s + 16 <= KS; s += 16) {              // two trips per iteration: static buffer indices
+        float a[8];
+        load_trip(s + 8, 1);
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + u)];
 #pragma unroll
         for (int u = 0; u < 8; u++)
 #pragma unroll
-            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[i][u], acc[i], 0, 0, 0);
+            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[0][i][u], acc[i], 0, 0, 0);
+        if (s + 24 <= KS) load_trip(s + 16, 0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + 8 + u)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[1][i][u], acc[i], 0, 0, 0);
+    }
+    if (s + 8 <= KS) {                           // one trip left (its fragments are in buffer 0)
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + u)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[0][i][u], acc[i], 0, 0, 0);
+        s += 8;
     }
     for (; s < KS; s++) {
         const float a = arow[4 * s];
