@@ -135,6 +135,15 @@ def main():
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
+    # a GPU box also grants a CPU QUOTA (cgroup v2 cpu.max = "quota period"): 256 visible CPUs but 16 cores' worth
+    # of time on a 1-GPU share; all ranks of a node share it
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            ncpu = min(ncpu, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
     threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(world, 1)))
     G = args.games
     if args.plumbing_test:
