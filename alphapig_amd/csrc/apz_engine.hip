@@ -105,6 +105,7 @@ struct apz_engine {
     int32_t* smp_mv = nullptr;
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
+    double* bn_sums = nullptr;                     // apz_bn_fwd / _bwd: per-channel reduction scratch
     float* wino_scratch[2] = {nullptr, nullptr};   // apz_wino_conv: rows16 input / output copies
     size_t wino_scratch_boards = 0;
     bool wgrad_attr_set[2] = {false, false};
@@ -524,7 +525,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1]};
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -1001,8 +1002,8 @@ int apz_wino_pack(apz_engine* e, const void* w_dev, int transpose_flip, void* up
 }
 
 int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, void* y_dev, int n, int relu,
-                  void* stream) {
-    if (!e || !x_dev || !upk_dev || !y_dev || n < 1) return fail(APZ_E_ARG, "bad argument");
+                  int layout, void* stream) {
+    if (!e || !x_dev || !upk_dev || !y_dev || n < 1 || layout < 0 || layout > 1) return fail(APZ_E_ARG, "bad argument");
     if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wino_conv: 15x15 boards only");
     std::lock_guard<std::mutex> guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -1011,7 +1012,7 @@ int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const v
         HIP_TRY(hipMemset(e->zeros256, 0, 256 * sizeof(float)));
     }
     StreamScope sc(e, stream);
-    if ((size_t)n > e->wino_scratch_boards) {   // grow the rows16 copies (previous users are ordered on their stream)
+    if (layout == APZ_LAYOUT_DENSE && (size_t)n > e->wino_scratch_boards) {   // grow the rows16 copies (previous users are ordered on their stream)
         HIP_TRY(hipDeviceSynchronize());
         for (int i = 0; i < 2; i++) {
             if (e->wino_scratch[i]) HIP_TRY(hipFree(e->wino_scratch[i]));
@@ -1031,26 +1032,33 @@ int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const v
     }
     const long planes = (long)n * 128;
     const int cgrid = (int)std::min<long>((planes * 240 + 255) / 256, 16384);
-    hipLaunchKernelGGL(apz::rows16_from_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, (const float*)x_dev,
-                       e->wino_scratch[0], planes);
+    const bool dense = layout == APZ_LAYOUT_DENSE;
+    const float* xin = dense ? e->wino_scratch[0] : (const float*)x_dev;
+    float* yout = dense ? e->wino_scratch[1] : (float*)y_dev;
+    if (dense)
+        hipLaunchKernelGGL(apz::rows16_from_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, (const float*)x_dev,
+                           e->wino_scratch[0], planes);
     const float* b = bias_dev ? (const float*)bias_dev : e->zeros256;
     const int grid = std::min((n + 1) / 2, e->num_cu);
     if (relu)
-        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream,
-                           e->wino_scratch[0], (const float*)upk_dev, b, nullptr, e->wino_scratch[1], n);
+        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, xin,
+                           (const float*)upk_dev, b, nullptr, yout, n);
     else
-        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream,
-                           e->wino_scratch[0], (const float*)upk_dev, b, nullptr, e->wino_scratch[1], n);
-    hipLaunchKernelGGL(apz::rows16_to_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, e->wino_scratch[1], (float*)y_dev,
-                       planes);
+        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, xin,
+                           (const float*)upk_dev, b, nullptr, yout, n);
+    if (dense)
+        hipLaunchKernelGGL(apz::rows16_to_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, e->wino_scratch[1],
+                           (float*)y_dev, planes);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
 
 int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, int cin, int cout,
-                      void* stream) {
-    if (!e || !x_dev || !dy_dev || !dw_dev || n < 1 || cin < 1 || cout < 32 || cout % 32)
+                      int layout, void* stream) {
+    if (!e || !x_dev || !dy_dev || !dw_dev || n < 1 || cin < 1 || cout < 32 || cout % 32 || layout < 0 || layout > 1)
         return fail(APZ_E_ARG, "bad argument (C_out must be a multiple of 32)");
+    if (layout == APZ_LAYOUT_ROWS16 && (e->cfg.height != 15 || e->cfg.width != 15))
+        return fail(APZ_E_UNSUPPORTED, "padded-row layout: 15x15 boards only");
     std::lock_guard<std::mutex> guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
@@ -1066,8 +1074,19 @@ int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void
             e->wgrad_attr_set[0] = true;
         }
         slices = std::max(1, std::min(n, e->num_cu / std::max(1, gx * gy)));   // 85 KB LDS: one workgroup per CU
-        hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<15, 15>), dim3(gx, gy, slices), dim3(256), G::LDS_BYTES, e->stream,
-                           (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
+        if (layout == APZ_LAYOUT_ROWS16) {
+            using G16 = apz::WgradGeo<15, 15, true>;
+            static bool set16 = false;
+            if (!set16) {
+                HIP_TRY(hipFuncSetAttribute((const void*)apz::conv3x3_wgrad_kernel<15, 15, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, G16::LDS_BYTES));
+                set16 = true;
+            }
+            hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<15, 15, true>), dim3(gx, gy, slices), dim3(256), G16::LDS_BYTES,
+                               e->stream, (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
+        } else
+            hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<15, 15>), dim3(gx, gy, slices), dim3(256), G::LDS_BYTES, e->stream,
+                               (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
     } else if (H == 8 && W == 8) {
         using G = apz::WgradGeo<8, 8>;
         if (!e->wgrad_attr_set[1]) {
@@ -1079,6 +1098,99 @@ int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void
                            (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
     } else {
         return fail(APZ_E_UNSUPPORTED, "conv3x3_wgrad: unsupported board size");
+    }
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+namespace {
+int bn_geometry(apz_engine* e, int layout, int* ps, int* rs) {
+    const int H = e->cfg.height, W = e->cfg.width;
+    if (layout == APZ_LAYOUT_DENSE) {
+        *ps = H * W, *rs = W;
+    } else if (layout == APZ_LAYOUT_ROWS16 && H == 15 && W == 15) {
+        *ps = 240, *rs = 16;
+    } else {
+        return fail(APZ_E_UNSUPPORTED, "padded-row layout: 15x15 boards only");
+    }
+    return APZ_OK;
+}
+int bn_sums(apz_engine* e) {   // [256][2] doubles, zeroed on the caller's stream
+    if (!e->bn_sums) HIP_TRY(hipMalloc((void**)&e->bn_sums, 256 * 2 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(e->bn_sums, 0, 256 * 2 * sizeof(double), e->stream));
+    return APZ_OK;
+}
+}  // namespace
+
+int apz_bn_fwd(apz_engine* e, const void* x_dev, const void* resid_dev, const void* gamma_dev, const void* beta_dev,
+               void* run_mean_dev, void* run_var_dev, void* y_dev, void* mean_dev, void* invstd_dev, int n, int C, int layout,
+               int relu, float momentum, float eps, void* stream) {
+    if (!e || !x_dev || !beta_dev || !y_dev || !mean_dev || !invstd_dev || n < 1 || C < 1 || C > 256)
+        return fail(APZ_E_ARG, "bad argument");
+    int ps, rs;
+    if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    if (int rc = bn_sums(e)) return rc;
+    const int H = e->cfg.height, W = e->cfg.width;
+    const int splits = std::max(1, std::min(n, (e->num_cu * 4) / C));
+    const bool r16 = layout == APZ_LAYOUT_ROWS16;
+    if (r16)
+        hipLaunchKernelGGL(apz::bn_stats_r16_kernel, dim3(C, std::max(1, std::min((n + 3) / 4, (e->num_cu * 8) / C))), dim3(256),
+                           0, e->stream, (const float*)x_dev, e->bn_sums, n, C);
+    else
+        hipLaunchKernelGGL(apz::bn_stats_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_sums, n, C,
+                           ps, rs, H, W);
+    hipLaunchKernelGGL(apz::bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, e->stream, e->bn_sums, (float*)mean_dev,
+                       (float*)invstd_dev, (float*)run_mean_dev, (float*)run_var_dev, C, (double)n * H * W, eps, momentum);
+    const long planes = (long)n * C;
+    const int grid = (int)std::min<long>((planes * ps + 255) / 256, 16384);
+    if (r16)
+        hipLaunchKernelGGL(apz::bn_apply_r16_kernel, dim3((int)std::min<long>((planes * 60 + 255) / 256, 16384)), dim3(256), 0,
+                           e->stream, (const float*)x_dev, (const float*)resid_dev, (const float*)gamma_dev,
+                           (const float*)beta_dev, (const float*)mean_dev, (const float*)invstd_dev, (float*)y_dev, planes, C,
+                           relu);
+    else
+        hipLaunchKernelGGL(apz::bn_apply_kernel, dim3(grid), dim3(256), 0, e->stream, (const float*)x_dev,
+                           (const float*)resid_dev, (const float*)gamma_dev, (const float*)beta_dev, (const float*)mean_dev,
+                           (const float*)invstd_dev, (float*)y_dev, planes, C, ps, rs, W, relu);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void* out_dev, const void* gamma_dev,
+               const void* mean_dev, const void* invstd_dev, void* dx_dev, void* dres_dev, void* dgamma_dev, void* dbeta_dev,
+               int n, int C, int layout, int relu, void* stream) {
+    if (!e || !dy_dev || !x_dev || !mean_dev || !invstd_dev || !dx_dev || n < 1 || C < 1 || C > 256 || (relu && !out_dev))
+        return fail(APZ_E_ARG, "bad argument");
+    int ps, rs;
+    if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    if (int rc = bn_sums(e)) return rc;
+    const int H = e->cfg.height, W = e->cfg.width;
+    const int splits = std::max(1, std::min(n, (e->num_cu * 4) / C));
+    const long planes = (long)n * C;
+    const int grid = (int)std::min<long>((planes * ps + 255) / 256, 16384);
+    if (layout == APZ_LAYOUT_ROWS16) {
+        hipLaunchKernelGGL(apz::bn_bwd_reduce_r16_kernel, dim3(C, std::max(1, std::min((n + 3) / 4, (e->num_cu * 8) / C))),
+                           dim3(256), 0, e->stream, (const float*)dy_dev, (const float*)x_dev, (const float*)out_dev,
+                           (const float*)mean_dev, (const float*)invstd_dev, e->bn_sums, n, C, relu);
+        hipLaunchKernelGGL(apz::bn_bwd_apply_r16_kernel, dim3((int)std::min<long>((planes * 60 + 255) / 256, 16384)), dim3(256),
+                           0, e->stream, (const float*)dy_dev, (const float*)x_dev, (const float*)out_dev,
+                           (const float*)gamma_dev, (const float*)mean_dev, (const float*)invstd_dev, (const double*)e->bn_sums,
+                           (float*)dx_dev, (float*)dres_dev, (float*)dgamma_dev, (float*)dbeta_dev, planes, C, relu,
+                           (double)n * H * W);
+    } else {
+        hipLaunchKernelGGL(apz::bn_bwd_reduce_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
+                           (const float*)x_dev, (const float*)out_dev, (const float*)mean_dev, (const float*)invstd_dev,
+                           e->bn_sums, n, C, ps, rs, H, W, relu);
+        hipLaunchKernelGGL(apz::bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, e->stream, (const float*)dy_dev,
+                           (const float*)x_dev, (const float*)out_dev, (const float*)gamma_dev, (const float*)mean_dev,
+                           (const float*)invstd_dev, (const double*)e->bn_sums, (float*)dx_dev, (float*)dres_dev,
+                           (float*)dgamma_dev, (float*)dbeta_dev, planes, C, ps, rs, W, relu, (double)n * H * W);
     }
     HIP_TRY(hipGetLastError());
     return APZ_OK;

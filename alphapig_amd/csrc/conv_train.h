@@ -116,9 +116,251 @@ __global__ void rows16_to_dense_kernel(const float* __restrict__ x, float* __res
     }
 }
 
-template <int H, int W>
+// ---- training-mode BatchNorm (+ residual, + ReLU) over [n][C][H][W] planes with plane stride PS and row
+// stride RS (dense NCHW: PS = H*W, RS = W; the trunk's padded-row layout: PS = 240, RS = 16).  Statistics are
+// over the n*H*W valid elements of a channel; pad columns (x >= W) are written as zero and never read.
+//   bn_stats_kernel      sums[c] += (sum x, sum x^2) in double (atomics; zeroed by the launcher); grid (C, splits)
+//   bn_finalize_kernel   mean, 1/sqrt(var + eps) per channel; moving statistics (torch semantics: unbiased
+//                        variance in the moving average, momentum = weight of the NEW value)
+//   bn_apply_kernel      y = act((x - mean) * invstd * gamma + beta (+ resid))
+//   bn_bwd_reduce_kernel sums[c] += (sum dz, sum dz * xhat), dz = dy (* [out > 0] with ReLU)
+//   bn_bwd_apply_kernel  dx = gamma * invstd * (dz - s1/M - xhat * s2/M); dres = dz
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int n, int C,
+                                                       int PS, int RS, int H, int W) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, HW = H * W;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = blockIdx.y; b < n; b += gridDim.y) {
+        const float* pl = x + ((size_t)b * C + c) * PS;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int y = p / W;
+            const float v = pl[y * RS + (p - y * W)];
+            s1 += v;
+            s2 += (double)v * v;
+        }
+    }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], s1);
+        atomicAdd(&sums[2 * c + 1], s2);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, int C, double M, float eps,
+                                   float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / M;
+    double var = sums[2 * c + 1] / M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) run_mean[c] = run_mean[c] * (1.f - momentum) + momentum * (float)m;
+    if (run_var) run_var[c] = run_var[c] * (1.f - momentum) + momentum * (float)(M > 1.0 ? var * M / (M - 1.0) : var);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       float* __restrict__ y, long planes, int C, int PS, int RS, int W,
+                                                       int relu) {
+    const long total = planes * PS;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pl = i / PS;
+        const int rem = (int)(i - pl * PS), col = rem % RS, c = (int)(pl % C);
+        float v = 0.f;
+        if (col < W) {
+            const float g = gamma ? gamma[c] : 1.f;
+            v = (x[i] - mean[c]) * invstd[c] * g + beta[c];
+            if (resid) v += resid[i];
+            if (relu) v = fmaxf(v, 0.f);
+        }
+        y[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ out, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, double* __restrict__ sums,
+                                                            int n, int C, int PS, int RS, int H, int W, int relu) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, HW = H * W;
+    const float m = mean[c], is = invstd[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = blockIdx.y; b < n; b += gridDim.y) {
+        const size_t base = ((size_t)b * C + c) * PS;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int y = p / W;
+            const size_t i = base + y * RS + (p - y * W);
+            float dz = dy[i];
+            if (relu && !(out[i] > 0.f)) dz = 0.f;
+            s1 += dz;
+            s2 += (double)dz * ((x[i] - m) * is);
+        }
+    }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], s1);
+        atomicAdd(&sums[2 * c + 1], s2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ out, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const double* __restrict__ sums, float* __restrict__ dx,
+                                                           float* __restrict__ dres, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, long planes, int C, int PS, int RS,
+                                                           int W, int relu, double M) {
+    const long total = planes * PS;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pl = i / PS;
+        const int rem = (int)(i - pl * PS), col = rem % RS, c = (int)(pl % C);
+        float gx = 0.f, gr = 0.f;
+        if (col < W) {
+            float dz = dy[i];
+            if (relu && !(out[i] > 0.f)) dz = 0.f;
+            const float xhat = (x[i] - mean[c]) * invstd[c];
+            const float g = gamma ? gamma[c] : 1.f;
+            gx = g * invstd[c] * (dz - (float)(sums[2 * c] / M) - xhat * (float)(sums[2 * c + 1] / M));
+            gr = dz;
+        }
+        dx[i] = gx;
+        if (dres) dres[i] = gr;
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dbeta) dbeta[c] = (float)sums[2 * c];
+            if (dgamma) dgamma[c] = (float)sums[2 * c + 1];
+        }
+}
+
+// ---- the same four kernels for the padded-row layout (plane = 60 float4; pad elements are zero on input, so
+// they add nothing to any sum, and are written back as zero): 16-byte accesses, no per-element index division
+__global__ __launch_bounds__(256) void bn_stats_r16_kernel(const float* __restrict__ x, double* __restrict__ sums, int n, int C) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;   // 4 boards per trip, 60 float4 each
+    double s1 = 0.0, s2 = 0.0;
+    if (sub < 4)
+        for (int b = blockIdx.y * 4 + sub; b < n; b += gridDim.y * 4) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x + ((size_t)b * C + c) * 240)[k];
+            s1 += (double)((v[0] + v[1]) + (v[2] + v[3]));
+            s2 += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+        }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    if (t == 0) {
+        atomicAdd(&sums[2 * c], s1);
+        atomicAdd(&sums[2 * c + 1], s2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_r16_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ y, long planes, int C, int relu) {
+    const long total = planes * 60;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long pl = v / 60;
+        const int c = (int)(pl % C);
+        const float sc = invstd[c] * (gamma ? gamma[c] : 1.f), sh = beta[c] - mean[c] * sc;
+        f32x4 a = reinterpret_cast<const f32x4*>(x)[v];
+        a = a * sc + sh;
+        if (resid) a += reinterpret_cast<const f32x4*>(resid)[v];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[e] = fmaxf(a[e], 0.f);
+        }
+        if ((v & 3) == 3) a[3] = 0.f;            // the pad column (60 float4 per plane: 4 per row)
+        reinterpret_cast<f32x4*>(y)[v] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_r16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ out, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, double* __restrict__ sums,
+                                                                int n, int C, int relu) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;
+    const float m = mean[c], is = invstd[c];
+    double s1 = 0.0, s2 = 0.0;
+    if (sub < 4)
+        for (int b = blockIdx.y * 4 + sub; b < n; b += gridDim.y * 4) {
+            const size_t o = ((size_t)b * C + c) * 60 + k;
+            f32x4 g = reinterpret_cast<const f32x4*>(dy)[o];
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x)[o];
+            if (relu) {
+                const f32x4 ov = reinterpret_cast<const f32x4*>(out)[o];
+#pragma unroll
+                for (int e = 0; e < 4; e++) g[e] = ov[e] > 0.f ? g[e] : 0.f;
+            }
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                a1 += g[e];
+                a2 += g[e] * ((xv[e] - m) * is);
+            }
+            s1 += a1;
+            s2 += a2;
+        }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    if (t == 0) {
+        atomicAdd(&sums[2 * c], s1);
+        atomicAdd(&sums[2 * c + 1], s2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_r16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ out, const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const double* __restrict__ sums, float* __restrict__ dx,
+                                                               float* __restrict__ dres, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, long planes, int C, int relu, double M) {
+    const long total = planes * 60;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long pl = v / 60;
+        const int c = (int)(pl % C);
+        const float m = mean[c], is = invstd[c], k0 = (float)(sums[2 * c] / M), k1 = (float)(sums[2 * c + 1] / M);
+        const float gi = (gamma ? gamma[c] : 1.f) * is;
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[v];
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[v];
+        if (relu) {
+            const f32x4 ov = reinterpret_cast<const f32x4*>(out)[v];
+#pragma unroll
+            for (int e = 0; e < 4; e++) g[e] = ov[e] > 0.f ? g[e] : 0.f;
+        }
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; e++) r[e] = gi * (g[e] - k0 - (xv[e] - m) * is * k1);
+        if ((v & 3) == 3) r[3] = 0.f, g[3] = 0.f;
+        reinterpret_cast<f32x4*>(dx)[v] = r;
+        if (dres) reinterpret_cast<f32x4*>(dres)[v] = g;
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dbeta) dbeta[c] = (float)sums[2 * c];
+            if (dgamma) dgamma[c] = (float)sums[2 * c + 1];
+        }
+}
+
+template <int H, int W, bool R16 = false>
 struct WgradGeo {
-    static constexpr int HW = H * W;
+    static constexpr int WP = R16 ? 16 : W;                         // stored row length (padded-row layout: 16)
+    static constexpr int HW = H * WP;                               // stored plane size = pixels walked by the k-steps
     static constexpr int RS = W + 1;
     static constexpr int XPLANE = (H + 2) * RS + 2;
     static constexpr int XPS = XPLANE | 1;                          // odd: 16 channel lanes -> 16 banks
@@ -138,10 +380,12 @@ struct WgradGeo {
 // before this board's MFMA loop and scattered into LDS after it, so HBM/L2 latency hides behind
 // ~1000 MFMAs per wave.  The epilogue transposes the accumulators through LDS so that every
 // atomic wave-instruction adds 64 consecutive floats of one dW row.
-template <int H, int W>
+// R16: x and dy in the trunk's padded-row layout [n][C][15][16] (pad column zero: it adds nothing to the sums)
+template <int H, int W, bool R16 = false>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dw, int n, int cin, int cout) {
-    using G = WgradGeo<H, W>;
+    using G = WgradGeo<H, W, R16>;
+    constexpr int WP = G::WP;
     constexpr int HW = G::HW, COT = G::COT;
     constexpr int XV = (64 * HW / 4 + 255) / 256;        // float4 pieces per thread: input tile
     constexpr int YV = (COT * 16 * HW / 4 + 255) / 256;  // dY tile
@@ -202,8 +446,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
                 const int idx = v * 4 + e;
                 if (idx < nci * HW) {
                     const int c = idx / HW, rem = idx - c * HW;
-                    const int yy = rem / W, xx = rem - yy * W;
-                    xt[c * G::XPS + (yy + 1) * G::RS + xx + 1] = px[u][e];
+                    const int yy = rem / WP, xx = rem - yy * WP;
+                    xt[c * G::XPS + (yy + 1) * G::RS + xx + 1] = px[u][e];   // (a pad element lands on the next row's zero halo)
                 }
             }
         }
@@ -246,7 +490,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
                             acc[c][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bv, acc[c][ky * 3 + kx], 0, 0, 0);
                     }
                 xx += 4;
-                if (xx >= W) { xx -= W; yy++; }
+                if (xx >= WP) { xx -= WP; yy++; }
             }
         }
     }

@@ -34,13 +34,18 @@ def _torch():
 
 class TorchTrainer(object):
     def __init__(self, params, net_kind="resnet", n_blocks=10, batch_size=512, wd=1e-4, device=None,
-                 dtype=None, dropout=0.5, seed=0, conv_backend="torch"):
+                 dtype=None, dropout=0.5, seed=0, conv_backend="torch", trunk_backend=None):
         torch = _torch()
         self.torch = torch
         self.kind, self.n_blocks = net_kind, n_blocks
         self.batch_size, self.wd, self.dropout = batch_size, wd, dropout
         # "hip": 3x3 convolutions (forward, dgrad, wgrad) on this repository's kernels (hipconv.py)
         self.conv_backend = conv_backend
+        # "hip16": the residual trunk end to end on HIP kernels in the self-play path's padded-row layout --
+        # Winograd pair kernel for forward / data gradient (no layout copies), weight-gradient kernel on the same
+        # layout, BatchNorm (+ residual) + ReLU forward and backward (hipconv.bn_act).  Default: on whenever the
+        # 3x3 convolutions are on HIP and the net is the 15x15 / 128-filter one; trunk_backend="torch" turns it off.
+        self.trunk_backend = trunk_backend
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
         self.device = torch.device(device)
@@ -81,12 +86,37 @@ class TorchTrainer(object):
         y = self._conv(x, self.p[name + "_weight"], self.p[name + "_bias"], k)
         return F.relu(self._bn(y, name, True, "_mean", "_var", train))
 
+    def _use_hip16(self, x, train):
+        if self.trunk_backend == "torch" or self.conv_backend != "hip" or not train or self.kind != "resnet":
+            return False
+        return (x.is_cuda and tuple(x.shape[1:]) == (128, 15, 15) and x.dtype == self.torch.float32 and
+                (self.trunk_backend == "hip16" or x.shape[0] >= 192))
+
+    def _trunk_hip16(self, x):
+        """The residual blocks on padded-row tensors [n][128][15][16] (training mode)."""
+        from . import hipconv
+        F = self.torch.nn.functional
+        x = F.pad(x, (0, 1))                     # dense -> padded rows (pad column zero)
+        p = self.p
+        for i in range(1, self.n_blocks + 1):
+            skip = x
+            y = hipconv.conv3x3(x, p["convA%d_weight" % i], p["convA%d_bias" % i], hipconv.ROWS16)
+            y = hipconv.bn_act(y, p["bnA%d_gamma" % i], p["bnA%d_beta" % i], p["bnA%d_moving_mean" % i],
+                               p["bnA%d_moving_var" % i], None, True, hipconv.ROWS16, 1.0 - BN_MOMENTUM, BN_EPS)
+            y = hipconv.conv3x3(y, p["convB%d_weight" % i], p["convB%d_bias" % i], hipconv.ROWS16)
+            x = hipconv.bn_act(y, p["bnB%d_gamma" % i], p["bnB%d_beta" % i], p["bnB%d_moving_mean" % i],
+                               p["bnB%d_moving_var" % i], skip, True, hipconv.ROWS16, 1.0 - BN_MOMENTUM, BN_EPS)
+        return x[..., :15].contiguous()
+
     def forward(self, states, train=True):
         torch, F = self.torch, self.torch.nn.functional
         x = states
         if self.kind == "resnet":
             x = self._conv_act(x, "res_conv1", 3, train)
-            for i in range(1, self.n_blocks + 1):
+            hip16 = self._use_hip16(x, train)
+            if hip16:
+                x = self._trunk_hip16(x)
+            for i in range(1, 0 if hip16 else self.n_blocks + 1):
                 skip = x
                 y = self._conv(x, self.p["convA%d_weight" % i], self.p["convA%d_bias" % i], 3)
                 y = F.relu(self._bn(y, "bnA%d" % i, False, "_moving_mean", "_moving_var", train))

@@ -132,8 +132,12 @@ int apz_conv3x3_pack(apz_engine *e, const void *w_dev, int cin, int cout, int tr
                      void *wpk_dev, void *stream);
 int apz_conv3x3_fwd(apz_engine *e, const void *x_dev, const void *wpk_dev, const void *bias_dev,
                     void *y_dev, int n, int cin_p, int cout_p, int relu, void *stream);
+/* activation layouts of the training primitives: dense NCHW, or the trunk's padded rows [n][C][15][16]
+ * (15x15 boards; pad column zero) in which the self-play kernels keep their activations */
+#define APZ_LAYOUT_DENSE 0
+#define APZ_LAYOUT_ROWS16 1
 int apz_conv3x3_wgrad(apz_engine *e, const void *x_dev, const void *dy_dev, void *dw_dev, int n,
-                      int cin, int cout, void *stream);
+                      int cin, int cout, int layout, void *stream);
 /* The same forward / data-gradient convolution for the trunk shape (128 -> 128 channels, 15x15) on the
  * fused Winograd F(4x4,3x3) kernel of the self-play path (csrc/trunk15_wino2.h):
  *   apz_wino_pack   w_dev [128][128][3][3] -> upk_dev (apz_wino_packed_size floats), U = G g G^T in fp32
@@ -143,7 +147,22 @@ int apz_conv3x3_wgrad(apz_engine *e, const void *x_dev, const void *dy_dev, void
 int64_t apz_wino_packed_size(void);
 int apz_wino_pack(apz_engine *e, const void *w_dev, int transpose_flip, void *upk_dev, void *stream);
 int apz_wino_conv(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev,
-                  void *y_dev, int n, int relu, void *stream);
+                  void *y_dev, int n, int relu, int layout, void *stream);
+/* Training-mode BatchNorm (+ residual) (+ ReLU), the reference's BatchNorm(eps = 1e-3) between the trunk's
+ * convolutions (policy_value_net_mxnet.py:41-102), over n x C planes in `layout`:
+ *   apz_bn_fwd  y = act((x - mean_c) * invstd_c * gamma_c + beta_c (+ resid)); batch statistics (biased
+ *               variance) written to mean_dev / invstd_dev [C] for the backward pass; run_mean / run_var
+ *               (may be NULL) updated as run = (1 - momentum) * run + momentum * batch (unbiased variance);
+ *               gamma_dev NULL = 1 (the reference's fix_gamma layers)
+ *   apz_bn_bwd  dz = dy (* [out > 0] with relu); dbeta = sum dz; dgamma = sum dz * xhat;
+ *               dx = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M); dres = dz (NULL: not wanted) */
+int apz_bn_fwd(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
+               const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
+               void *invstd_dev, int n, int C, int layout, int relu, float momentum, float eps, void *stream);
+int apz_bn_bwd(apz_engine *e, const void *dy_dev, const void *x_dev, const void *out_dev,
+               const void *gamma_dev, const void *mean_dev, const void *invstd_dev, void *dx_dev,
+               void *dres_dev, void *dgamma_dev, void *dbeta_dev, int n, int C, int layout, int relu,
+               void *stream);
 
 int apz_sync(apz_engine *e);
 void *apz_stream(apz_engine *e);

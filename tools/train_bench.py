@@ -27,11 +27,13 @@ def main():
         states = (rs.rand(B, 9, 15, 15) > 0.7).astype(np.float32)
         pis = rs.dirichlet(np.ones(225), size=B).astype(np.float32)
         zs = rs.choice([-1.0, 1.0], size=B).astype(np.float32)
-        for backend in ("torch", "hip-direct", "hip-wino", "hip"):
-            # "hip": the default choice (Winograd pair kernel for forward / dgrad of the trunk shape from 192 boards)
+        for backend in ("torch", "hip-direct", "hip-wino", "hip16", "hip"):
+            # "hip": the default choice (from 192 boards: the whole trunk on HIP kernels in the padded-row layout =
+            # "hip16"); "hip-direct" / "hip-wino": dense tensors, torch BatchNorm, direct / Winograd forward + dgrad
             os.environ["APZ_TRAIN_CONV"] = {"hip-direct": "direct", "hip-wino": "wino"}.get(backend, "auto")
             tr = TorchTrainer(prm, "resnet", n_blocks=10, batch_size=B, device="cuda",
-                              conv_backend="torch" if backend == "torch" else "hip")
+                              conv_backend="torch" if backend == "torch" else "hip",
+                              trunk_backend={"hip16": "hip16", "hip": None}.get(backend, "torch"))
             for _ in range(3):
                 tr.train_step(states, pis, zs, 1e-3)
             torch.cuda.synchronize()
