@@ -106,6 +106,8 @@ struct apz_engine {
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     double* bn_sums = nullptr;                     // apz_bn_fwd / _bwd: per-channel reduction scratch
+    void* adam_tab = nullptr;                      // apz_adam_step: device copy of the tensor table
+    size_t adam_cap = 0;
     float* wino_scratch[2] = {nullptr, nullptr};   // apz_wino_conv: rows16 input / output copies
     size_t wino_scratch_boards = 0;
     bool wgrad_attr_set[2] = {false, false};
@@ -525,7 +527,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums};
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -1192,6 +1194,28 @@ int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void*
                            (const float*)invstd_dev, (const double*)e->bn_sums, (float*)dx_dev, (float*)dres_dev,
                            (float*)dgamma_dev, (float*)dbeta_dev, planes, C, ps, rs, W, relu, (double)n * H * W);
     }
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_adam_step(apz_engine* e, const void* table_host, int ntensors, float lr_t, float b1, float b2, float eps,
+                  float rescale, void* stream) {
+    if (!e || !table_host || ntensors < 1 || ntensors > 4096) return fail(APZ_E_ARG, "bad argument");
+    static_assert(sizeof(apz::AdamTensor) == 48, "apz_adam_tensor layout");
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    const size_t bytes = (size_t)ntensors * sizeof(apz::AdamTensor);
+    if (bytes > e->adam_cap) {
+        if (e->adam_tab) HIP_TRY(hipFree(e->adam_tab));
+        e->adam_tab = nullptr;
+        HIP_TRY(hipMalloc((void**)&e->adam_tab, bytes));
+        e->adam_cap = bytes;
+    }
+    // pageable source: the copy is staged by the runtime before this call returns, and ordered on the stream
+    HIP_TRY(hipMemcpyAsync(e->adam_tab, table_host, bytes, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(apz::adam_step_kernel, dim3(32, ntensors), dim3(256), 0, e->stream,
+                       (const apz::AdamTensor*)e->adam_tab, lr_t, b1, b2, eps, rescale);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }

@@ -248,6 +248,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         }
 }
 
+// ---- Adam as Module.init_optimizer configures it in the reference (policy_value_net_mxnet.py:198-205): ONE launch over
+// every trainable tensor (blockIdx.y = tensor).  g = grad * rescale + wd * w;  m = b1 m + (1-b1) g;
+// v = b2 v + (1-b2) g^2;  w -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) from the host.
+struct AdamTensor {
+    float* w;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;
+    float wd;
+    int pad_;
+};
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamTensor* __restrict__ tab, float lr_t, float b1, float b2,
+                                                        float eps, float rescale) {
+    const AdamTensor T = tab[blockIdx.y];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < T.n; i += (long long)gridDim.x * blockDim.x) {
+        const float w = T.w[i];
+        const float g = T.g[i] * rescale + T.wd * w;
+        const float m = T.m[i] * b1 + (1.f - b1) * g;
+        const float v = T.v[i] * b2 + (1.f - b2) * (g * g);
+        T.m[i] = m;
+        T.v[i] = v;
+        T.w[i] = w - lr_t * m / (sqrtf(v) + eps);
+    }
+}
+
 // ---- the same four kernels for the padded-row layout (plane = 60 float4; pad elements are zero on input, so
 // they add nothing to any sum, and are written back as zero): 16-byte accesses, no per-element index division
 __global__ __launch_bounds__(256) void bn_stats_r16_kernel(const float* __restrict__ x, double* __restrict__ sums, int n, int C) {

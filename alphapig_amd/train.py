@@ -165,16 +165,41 @@ class TorchTrainer(object):
         b1, b2, eps = 0.9, 0.999, 1e-8
         lr_t = learning_rate * (1.0 - b2 ** self.t) ** 0.5 / (1.0 - b1 ** self.t)
         rescale = 1.0 / self.batch_size
-        with torch.no_grad():
-            for k in self.train_names:
-                w = self.p[k]
-                g = w.grad if w.grad is not None else torch.zeros_like(w)
-                wd = self.wd if k.endswith(("_weight", "_gamma")) else 0.0
-                g = g * rescale + wd * w
-                self.m[k].mul_(b1).add_(g, alpha=1.0 - b1)
-                self.v[k].mul_(b2).addcmul_(g, g, value=1.0 - b2)
-                w.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + eps))
+        if self.conv_backend == "hip" and self.device.type == "cuda" and self.dtype == torch.float32:
+            self._adam_hip(lr_t, b1, b2, eps, rescale)        # one launch over all tensors
+        else:
+            with torch.no_grad():
+                for k in self.train_names:
+                    w = self.p[k]
+                    g = w.grad if w.grad is not None else torch.zeros_like(w)
+                    wd = self.wd if k.endswith(("_weight", "_gamma")) else 0.0
+                    g = g * rescale + wd * w
+                    self.m[k].mul_(b1).add_(g, alpha=1.0 - b1)
+                    self.v[k].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                    w.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + eps))
         return float(loss.detach().cpu()), float(entropy.detach().cpu())
+
+    def _adam_hip(self, lr_t, b1, b2, eps, rescale):
+        """The same update as the loop above through apz_adam_step: a table of (w, grad, m, v, n, wd) per tensor."""
+        import ctypes as C
+        from . import _native, hipconv
+        torch = self.torch
+        tab = np.zeros(len(self.train_names), dtype=[("w", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"),
+                                                     ("wd", "f4"), ("pad", "i4")])
+        keep = []
+        for i, k in enumerate(self.train_names):
+            w = self.p[k]
+            g = w.grad if w.grad is not None else torch.zeros_like(w)
+            g = g.contiguous()
+            keep.append(g)
+            tab[i] = (w.data_ptr(), g.data_ptr(), self.m[k].data_ptr(), self.v[k].data_ptr(), w.numel(),
+                      self.wd if k.endswith(("_weight", "_gamma")) else 0.0, 0)
+        L = _native.hip()
+        hnd = hipconv._engine(15, 15, self.device.index or 0)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = L.apz_adam_step(hnd, tab.ctypes.data_as(C.c_void_p), len(tab), lr_t, b1, b2, eps, rescale, stream)
+        if rc < 0:
+            raise RuntimeError(L.apz_last_error().decode())
 
     def policy_value(self, state_batch):
         """Inference-mode (moving statistics) probabilities and values, for the KL monitor."""

@@ -159,6 +159,13 @@ int apz_wino_conv(apz_engine *e, const void *x_dev, const void *upk_dev, const v
 int apz_bn_fwd(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
                const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
                void *invstd_dev, int n, int C, int layout, int relu, float momentum, float eps, void *stream);
+/* One optimiser step of the reference's Adam (policy_value_net_mxnet.py:198-205: rescale_grad = 1/batch_size,
+ * wd on *_weight / *_gamma) over ntensors device tensors in ONE launch.  table_host: ntensors entries
+ * { float *w; const float *g; float *m; float *v; int64 n; float wd; int32 pad; } (48 bytes) in HOST memory;
+ * g = g * rescale + wd * w; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g*g; w -= lr_t * m / (sqrt(v) + eps),
+ * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) computed by the caller. */
+int apz_adam_step(apz_engine *e, const void *table_host, int ntensors, float lr_t, float b1, float b2,
+                  float eps, float rescale, void *stream);
 int apz_bn_bwd(apz_engine *e, const void *dy_dev, const void *x_dev, const void *out_dev,
                const void *gamma_dev, const void *mean_dev, const void *invstd_dev, void *dx_dev,
                void *dres_dev, void *dgamma_dev, void *dbeta_dev, int n, int C, int layout, int relu,
