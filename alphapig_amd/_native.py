@@ -104,7 +104,7 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_forward_host", "apz_forward_codes_host", "apz_forward_codes_async", "apz_submit_codes", "apz_wait", "apz_host_alloc",
                "apz_host_free", "apz_encode_planes", "apz_augment8", "apz_sample_moves_host", "apz_conv3x3_packed_size", "apz_conv3x3_pack",
                "apz_conv3x3_fwd", "apz_conv3x3_wgrad", "apz_wino_packed_size", "apz_wino_pack", "apz_wino_conv",
-               "apz_bn_fwd", "apz_bn_bwd", "apz_adam_step",
+               "apz_bn_fwd", "apz_bn_bwd", "apz_adam_step", "apz_wgrad_wino",
                "apz_sync", "apz_stream",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
                "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms"]
@@ -151,6 +151,7 @@ def hip():
         "apz_wino_conv": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "apz_bn_fwd": (C.c_int, [vp] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
         "apz_bn_bwd": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_wgrad_wino": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
         "apz_adam_step": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "apz_sync": (C.c_int, [vp]),
         "apz_stream": (vp, [vp]),

@@ -19,6 +19,7 @@
 #include "trunk15_ring.h"
 #include "trunk15_wino.h"
 #include "trunk15_wino2.h"
+#include "wgrad_wino.h"
 #include "sampler.h"
 #include "conv_train.h"
 
@@ -106,6 +107,8 @@ struct apz_engine {
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     double* bn_sums = nullptr;                     // apz_bn_fwd / _bwd: per-channel reduction scratch
+    float* wgw_scratch = nullptr;                  // apz_wgrad_wino: partial dU per batch slice
+    int wgw_slices = 0;
     void* adam_tab = nullptr;                      // apz_adam_step: device copy of the tensor table
     size_t adam_cap = 0;
     float* wino_scratch[2] = {nullptr, nullptr};   // apz_wino_conv: rows16 input / output copies
@@ -527,7 +530,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab};
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -1194,6 +1197,37 @@ int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void*
                            (const float*)invstd_dev, (const double*)e->bn_sums, (float*)dx_dev, (float*)dres_dev,
                            (float*)dgamma_dev, (float*)dbeta_dev, planes, C, ps, rs, W, relu, (double)n * H * W);
     }
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, void* stream) {
+    if (!e || !x_dev || !dy_dev || !dw_dev || n < 1) return fail(APZ_E_ARG, "bad argument");
+    if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wgrad_wino: 15x15 boards only");
+    using T = apz::WgradWino;
+    std::lock_guard<std::mutex> guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    const int slices = std::max(1, std::min(n, e->num_cu / T::GROUPS));       // 12 position groups x slices ~ one per CU
+    if (slices > e->wgw_slices) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (e->wgw_scratch) HIP_TRY(hipFree(e->wgw_scratch));
+        e->wgw_scratch = nullptr;
+        HIP_TRY(hipMalloc((void**)&e->wgw_scratch, (size_t)slices * T::SCRATCH_FLOATS_PER_SLICE * sizeof(float)));
+        e->wgw_slices = slices;
+    }
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T::LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL(apz::wgrad_wino_kernel, dim3(T::GROUPS, slices), dim3(512), T::LDS_BYTES, e->stream, (const float*)x_dev,
+                       (const float*)dy_dev, e->wgw_scratch, n);
+    hipLaunchKernelGGL(apz::wgrad_wino_sum_kernel, dim3(36 * 128 * 128 / 4 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
+                       slices);
+    hipLaunchKernelGGL(apz::wgrad_wino_reduce_kernel, dim3(128 * 128 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
+                       (float*)dw_dev);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }

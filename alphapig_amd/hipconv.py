@@ -115,7 +115,11 @@ def _function():
                     dx = torch.nn.grad.conv2d_input(x.shape, weight, dy, padding=1)
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight)
-                _ck(L, L.apz_conv3x3_wgrad(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, ci, co, layout, stream))
+                import os
+                if layout == ROWS16 and n >= 64 and os.environ.get("APZ_TRAIN_WGRAD", "wino") != "direct":
+                    _ck(L, L.apz_wgrad_wino(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, stream))
+                else:
+                    _ck(L, L.apz_conv3x3_wgrad(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, ci, co, layout, stream))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = dy.sum(dim=(0, 2, 3))       # (pad columns of a padded-row gradient are zero)
             return dx, dw, db, None

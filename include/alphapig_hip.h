@@ -159,6 +159,10 @@ int apz_wino_conv(apz_engine *e, const void *x_dev, const void *upk_dev, const v
 int apz_bn_fwd(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
                const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
                void *invstd_dev, int n, int C, int layout, int relu, float momentum, float eps, void *stream);
+/* Weight gradient of the trunk shape (128 -> 128, 15x15) through the Winograd domain (csrc/wgrad_wino.h; 3.6x fewer
+ * MFMAs than apz_conv3x3_wgrad): x_dev / dy_dev in the padded-row layout [n][128][15][16], dw_dev [128][128][3][3]
+ * overwritten. */
+int apz_wgrad_wino(apz_engine *e, const void *x_dev, const void *dy_dev, void *dw_dev, int n, void *stream);
 /* One optimiser step of the reference's Adam (policy_value_net_mxnet.py:198-205: rescale_grad = 1/batch_size,
  * wd on *_weight / *_gamma) over ntensors device tensors in ONE launch.  table_host: ntensors entries
  * { float *w; const float *g; float *m; float *v; int64 n; float wd; int32 pad; } (48 bytes) in HOST memory;

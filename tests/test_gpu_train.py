@@ -159,3 +159,26 @@ def test_trainer_hip16_trunk_matches_torch_graph():
         d = np.abs(out["hip16"][1][k] - out["torch"][1][k])
         assert int((d > 2e-4).sum()) <= max(8, 0.01 * d.size), k     # (Adam sign flips on noise-level gradients, see above)
         assert float(d.max()) < 2 * 1e-3 * 3 + 2e-4, k
+
+
+@pytest.mark.parametrize("n", [64, 130, 513])
+def test_winograd_domain_weight_gradient(n, monkeypatch):
+    """apz_wgrad_wino (padded-row layout, used from 64 boards on) against torch float64 and against the direct
+    weight-gradient kernel on the same tensors."""
+    from alphapig_amd import hipconv
+    g = torch.Generator().manual_seed(4000 + n)
+    x = torch.randn(n, 128, 15, 15, generator=g)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34.0).float()
+    dy = torch.randn(n, 128, 15, 15, generator=g)
+    w64 = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), w64, None, padding=1).backward(dy.double())
+    pad = lambda t: torch.nn.functional.pad(t, (0, 1))
+    got = {}
+    for mode in ("wino", "direct"):
+        monkeypatch.setenv("APZ_TRAIN_WGRAD", mode)
+        wc = w.cuda().requires_grad_(True)
+        y = hipconv.conv3x3(pad(x).cuda(), wc, None, hipconv.ROWS16)
+        y.backward(pad(dy).cuda())
+        torch.cuda.synchronize()
+        got[mode] = wc.grad.cpu().double()
+        assert float((got[mode] - w64.grad).abs().max()) < 1e-4 * float(w64.grad.abs().max()), mode
