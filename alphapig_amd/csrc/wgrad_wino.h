@@ -56,6 +56,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const float* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, j = lane & 15;
     const int gi = blockIdx.x;                       // transformed row i: the workgroup's positions are (i, 0..5)
+    const int wa = wave >> 2, wb = wave & 3;         // MFMA phase: output-channel half, input-channel quarter
 
     for (int i = tid; i < T::RAWX_FLOATS; i += 512) rawx[i] = 0.f;   // halo cells stay zero
 
@@ -119,14 +120,20 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const float* __restrict
             __syncthreads();
             // ---- transform this chunk's units to the workgroup's three positions
             if (is_x) {
-                const float* rp = rawx + T::RFRONT + uch * T::RPS + (4 * uty - 1) * T::RROW + 4 * utx - 1;
-                float r[6];                          // row i of B^T d, six columns
+                // the 6x6 patch row by row: column -1, columns 0..3 (one aligned 16-byte read), column 4
+                const float* rp = rawx + T::RFRONT + uch * T::RPS + (4 * uty - 1) * T::RROW + 4 * utx;
+                float r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // row i of B^T d, six columns
 #pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    float acc1 = 0.f;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) acc1 = __builtin_fmaf(cbr[a], rp[a * T::RROW + k], acc1);
-                    r[k] = acc1;
+                for (int a = 0; a < 6; a++) {
+                    const float cm1 = rp[a * T::RROW - 1];
+                    const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + a * T::RROW);
+                    const float c4 = rp[a * T::RROW + 4];
+                    r[0] = __builtin_fmaf(cbr[a], cm1, r[0]);
+                    r[1] = __builtin_fmaf(cbr[a], c03[0], r[1]);
+                    r[2] = __builtin_fmaf(cbr[a], c03[1], r[2]);
+                    r[3] = __builtin_fmaf(cbr[a], c03[2], r[3]);
+                    r[4] = __builtin_fmaf(cbr[a], c03[3], r[4]);
+                    r[5] = __builtin_fmaf(cbr[a], c4, r[5]);
                 }
 #pragma unroll
                 for (int kk = 0; kk < 6; kk++) {
@@ -138,15 +145,13 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const float* __restrict
                 }
             } else {
                 const float* yp = rawy + uch * T::GPLANE + (4 * uty) * 16 + 4 * utx;
-                float r[4];                          // row i of A dY, four columns
+                f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};   // row i of A dY, four columns (one 16-byte read per tile row)
 #pragma unroll
-                for (int bcol = 0; bcol < 4; bcol++) {
-                    float acc1 = 0.f;
-#pragma unroll
-                    for (int a = 0; a < 4; a++)
-                        acc1 = __builtin_fmaf(car[a], (4 * uty + a < 15) ? yp[a * 16 + bcol] : 0.f, acc1);
-                    r[bcol] = acc1;
+                for (int a = 0; a < 4; a++) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(yp + (4 * uty + a < 15 ? a : 0) * 16);
+                    r4 += (4 * uty + a < 15 ? car[a] : 0.f) * v;
                 }
+                const float r[4] = {r4[0], r4[1], r4[2], r4[3]};
 #pragma unroll
                 for (int kk = 0; kk < 6; kk++) {
                     float o = 0.f;
@@ -159,20 +164,25 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const float* __restrict
         }
         }
         __syncthreads();                             // both operand arrays complete for board b
-        // ---- dU[pos][co 16w..][ci] += dM[pos][co][tile] * V[pos][ci][tile]:  A = dM (m = co), B = V (n = ci), k = tile
+        // ---- dU[pos][co][ci] += dM[pos][co][tile] * V[pos][ci][tile]:  A = dM (m = co), B = V (n = ci), k = tile.
+        // wave = (co half wa: four 16-channel tiles, ci quarter wb: two tiles): 4 + 2 operand reads per 8 MFMAs
 #pragma unroll
         for (int p = 0; p < T::NPOS; p++)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const float a = opm[(p * 16 + 4 * s + q) * T::OPS + wave * 16 + j];
+                const float* om = opm + (p * 16 + 4 * s + q) * T::OPS + wa * 64 + j;
+                const float* ov = opv + (p * 16 + 4 * s + q) * T::OPS + wb * 32 + j;
+                const float b0 = ov[0], b1 = ov[16];
 #pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const float bv = opv[(p * 16 + 4 * s + q) * T::OPS + t * 16 + j];
-                    acc[p][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[p][t], 0, 0, 0);
+                for (int t = 0; t < 4; t++) {
+                    const float a = om[t * 16];
+                    acc[p][2 * t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[p][2 * t], 0, 0, 0);
+                    acc[p][2 * t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[p][2 * t + 1], 0, 0, 0);
                 }
             }
     }
-    // ---- partial dU of this slice: lane (q, j), register r -> co = 16*wave + 4q + r, ci = 16t + j
+    // ---- partial dU of this slice: accumulator (t, u), lane (q, j), register r -> co = 64 wa + 16 t + 4q + r,
+    // ci = 32 wb + 16 u + j
     float* out = scratch + (size_t)blockIdx.y * T::SCRATCH_FLOATS_PER_SLICE;
 #pragma unroll
     for (int p = 0; p < T::NPOS; p++) {
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const float* __restrict
         for (int t = 0; t < 8; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                out[((size_t)pos * T::C + wave * 16 + 4 * q + r) * T::C + t * 16 + j] = acc[p][t][r];
+                out[((size_t)pos * T::C + wa * 64 + (t >> 1) * 16 + 4 * q + r) * T::C + wb * 32 + (t & 1) * 16 + j] = acc[p][t][r];
     }
 }
 
