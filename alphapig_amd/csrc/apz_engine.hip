@@ -1081,7 +1081,7 @@ int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void
         slices = std::max(1, std::min(n, e->num_cu / std::max(1, gx * gy)));   // 85 KB LDS: one workgroup per CU
         if (layout == APZ_LAYOUT_ROWS16) {
             using G16 = apz::WgradGeo<15, 15, true>;
-            static bool set16 = false;
+            bool& set16 = e->lds_attr_set[8];       // per engine (= per device), like every other attribute flag
             if (!set16) {
                 HIP_TRY(hipFuncSetAttribute((const void*)apz::conv3x3_wgrad_kernel<15, 15, true>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, G16::LDS_BYTES));
@@ -1216,7 +1216,7 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
         HIP_TRY(hipMalloc((void**)&e->wgw_scratch, (size_t)slices * T::SCRATCH_FLOATS_PER_SLICE * sizeof(float)));
         e->wgw_slices = slices;
     }
-    static bool attr = false;
+    bool& attr = e->lds_attr_set[9];
     if (!attr) {
         HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T::LDS_BYTES));
