@@ -34,12 +34,14 @@ def _torch():
 
 class TorchTrainer(object):
     def __init__(self, params, net_kind="resnet", n_blocks=10, batch_size=512, wd=1e-4, device=None,
-                 dtype=None, dropout=0.5, seed=0, conv_backend="torch", trunk_backend=None):
+                 dtype=None, dropout=0.5, seed=0, conv_backend=None, trunk_backend=None):
         torch = _torch()
         self.torch = torch
         self.kind, self.n_blocks = net_kind, n_blocks
         self.batch_size, self.wd, self.dropout = batch_size, wd, dropout
-        # "hip": 3x3 convolutions (forward, dgrad, wgrad) on this repository's kernels (hipconv.py)
+        # "hip": 3x3 convolutions (forward, dgrad, wgrad), the trunk's BatchNorm and Adam on this repository's
+        # kernels (hipconv.py) -- the default on a GPU; "torch": everything in PyTorch (the CPU path, and the
+        # reference graph the HIP path is tested against)
         self.conv_backend = conv_backend
         # "hip16": the residual trunk end to end on HIP kernels in the self-play path's padded-row layout --
         # Winograd pair kernel for forward / data gradient (no layout copies), weight-gradient kernel on the same
@@ -50,6 +52,8 @@ class TorchTrainer(object):
             device = "cuda" if torch.cuda.is_available() else "cpu"
         self.device = torch.device(device)
         self.dtype = dtype or torch.float32
+        if self.conv_backend is None:
+            self.conv_backend = "hip" if (self.device.type == "cuda" and self.dtype == torch.float32) else "torch"
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         self.p = collections.OrderedDict()
