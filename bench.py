@@ -27,7 +27,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before numpy / torch load an OpenMP runtime (see alphapig_amd/_native.py)
+if "GOMP_SPINCOUNT" not in os.environ and "OMP_WAIT_POLICY" not in os.environ:
+    os.environ["GOMP_SPINCOUNT"] = "100000"   # before numpy / torch load an OpenMP runtime (see alphapig_amd/_native.py)
 
 import numpy as np  # noqa: E402
 
