@@ -454,9 +454,13 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
     const int hw = e->hw;
     {
         Timed tm(e, APZ_K_HEAD_CONV);
-        hipLaunchKernelGGL(apz::head_conv1x1_kernel, dim3(std::min(n, e->num_cu * 8)), dim3(256), 0, e->stream, trunk,
-                           e->w6, e->b6, e->featp, e->featv, n, e->clast, hw, e->cfg.width,
-                           e->ring ? e->act_ps : hw, e->ring ? e->act_rs : e->cfg.width);
+        if (e->ring && e->clast % 8 == 0)
+            hipLaunchKernelGGL(apz::head_conv1x1_r16_kernel, dim3((n + 3) / 4), dim3(256), 0, e->stream, trunk, e->w6, e->b6,
+                               e->featp, e->featv, n, e->clast);
+        else
+            hipLaunchKernelGGL(apz::head_conv1x1_kernel, dim3(std::min(n, e->num_cu * 8)), dim3(256), 0, e->stream, trunk,
+                               e->w6, e->b6, e->featp, e->featv, n, e->clast, hw, e->cfg.width,
+                               e->ring ? e->act_ps : hw, e->ring ? e->act_rs : e->cfg.width);
         HIP_TRY(hipGetLastError());
     }
     {

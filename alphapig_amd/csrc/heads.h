@@ -65,6 +65,41 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   D  lane l, reg r: board = (l>>4)*4 + r, out = nt*16 + (l&15)
 // TPW = n-tiles per wave (ceil(NTILE / 4)); each wave keeps TPW independent accumulators so
 // the 40-cycle dependent-MFMA latency is covered.
+// The same two 1x1 head convolutions for the trunk's padded-row activations [n][C][15][16]: a thread owns one
+// 16-byte piece (4 pixels of a row) of a board and walks the C planes with 16-byte loads, eight in flight;
+// 4 boards per workgroup (240 of 256 threads).  Reads C*960 bytes per board once, coalesced.
+__global__ __launch_bounds__(256) void head_conv1x1_r16_kernel(const float* __restrict__ x, const float* __restrict__ w6,
+                                                               const float* __restrict__ b6, float* __restrict__ featp,
+                                                               float* __restrict__ featv, int n, int C) {
+    const int t = threadIdx.x, sub = t / 60, k = t - sub * 60;
+    const int b = blockIdx.x * 4 + sub;
+    if (sub >= 4 || b >= n) return;
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * C * 240) + k;
+    f32x4 acc[6];
+#pragma unroll
+    for (int o = 0; o < 6; o++) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = xb[(size_t)(c0 + u) * 60];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int o = 0; o < 6; o++) acc[o] += w6[o * C + c0 + u] * v[u];
+    }
+    const int row = k >> 2, col0 = (k & 3) * 4;
+    float* fp = featp + (size_t)b * 4 * 225 + row * 15 + col0;
+    float* fv = featv + (size_t)b * 2 * 225 + row * 15 + col0;
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        if (col0 + e < 15) {
+#pragma unroll
+            for (int o = 0; o < 4; o++) fp[o * 225 + e] = fmaxf(acc[o][e] + b6[o], 0.f);
+#pragma unroll
+            for (int o = 0; o < 2; o++) fv[o * 225 + e] = fmaxf(acc[4 + o][e] + b6[4 + o], 0.f);
+        }
+}
+
 template <int TPW>
 __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ featp, const float* __restrict__ featv,
                                                       const float* __restrict__ wfc_pk, const float* __restrict__ bfc,
