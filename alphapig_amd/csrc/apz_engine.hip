@@ -734,12 +734,14 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
         }
         const float* wfc = P.at("fc_3_1_1_weight");   // [hw][4*hw]
         const int K = 4 * hw, KS = hw, ntile = (hw + 15) / 16;
-        std::vector<float> pk((size_t)ntile * KS * 64, 0.f);
+        // head_fc_kernel: [tile][trip of 8 k-steps][lane][8], zero past KS and past hw outputs
+        const int KG = (KS + 7) / 8;
+        std::vector<float> pk((size_t)ntile * KG * 64 * 8, 0.f);
         for (int nt = 0; nt < ntile; nt++)
             for (int s = 0; s < KS; s++)
                 for (int lane = 0; lane < 64; lane++) {
                     const int o = nt * 16 + (lane & 15), k = 4 * s + (lane >> 4);
-                    if (o < hw) pk[((size_t)nt * KS + s) * 64 + lane] = wfc[(size_t)o * K + k];
+                    if (o < hw) pk[((((size_t)nt * KG + (s >> 3)) * 64 + lane) << 3) + (s & 7)] = wfc[(size_t)o * K + k];
                 }
         std::vector<float> bfc(P.at("fc_3_1_1_bias"), P.at("fc_3_1_1_bias") + hw);
         std::vector<float> wv(P.at("fc_3_2_1_weight"), P.at("fc_3_2_1_weight") + 2 * hw);

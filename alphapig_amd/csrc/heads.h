@@ -117,10 +117,32 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
     const int b0 = blockIdx.x * 16;
     const int nb = min(16, n - b0);
 
-    // stage 16 feature rows (zero rows beyond n)
-    for (int i = tid; i < 16 * K; i += 256) {
-        const int r = i / K, c = i - r * K;
-        sm[r * ldf + c] = (r < nb) ? featp[(size_t)(b0 + r) * K + c] : 0.f;
+    // stage 16 feature rows (zero rows beyond n): the rows are one contiguous block of 16*K floats, K a multiple
+    // of 4 -- all 16-byte loads of a thread are issued before the first LDS store (one memory latency, not one per
+    // loop trip: the staging was a third of the kernel's time)
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(featp + (size_t)b0 * K);
+        const int n4 = 16 * K / 4;
+        constexpr int NV = 16;                  // >= 16*K/4/256 for K <= 1024
+        f32x4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const int i4 = tid + 256 * u;
+            const int r = (4 * i4) / K;
+            v[u] = (i4 < n4 && r < nb) ? src[i4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const int i4 = tid + 256 * u;
+            if (i4 < n4) {
+                const int r = (4 * i4) / K, c = 4 * i4 - r * K;
+                float* d = sm + r * ldf + c;
+                d[0] = v[u][0];
+                d[1] = v[u][1];
+                d[2] = v[u][2];
+                d[3] = v[u][3];
+            }
+        }
     }
     __syncthreads();
 
@@ -128,57 +150,40 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < TPW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* arow = sm + j * ldf + q;
-    // K loop, 8 k-steps per trip so that the 8 x TPW weight-fragment loads (L2) of a trip are in
-    // flight together instead of one dependent L2 round trip per MFMA (KS = H*W: 225 = 28*8 + 1);
-    // the NEXT trip's fragments are loaded before this trip's MFMAs issue (register double buffer),
-    // so the L2 latency of a trip hides behind the 8 x TPW MFMAs of the previous one.
-    int s = 0;
-    float bw[2][TPW][8];
-    auto load_trip = [&](int s0, int buf) {
+    // K loop in trips of 8 k-steps.  wfc_pk is [tile][trip][lane][8]: a lane's eight weights of a trip are 32
+    // contiguous bytes (two 16-byte loads; a wave reads 2 KB contiguously), zero-padded past KS.  The NEXT
+    // trip's fragments are loaded before this trip's MFMAs issue (register double buffer), so the L2 latency
+    // of a trip hides behind the 8 x TPW MFMAs of the previous one.
+    const int KG = (KS + 7) / 8;
+    f32x4 bw[2][TPW][2];
+    auto load_trip = [&](int g, int buf) {
 #pragma unroll
         for (int i = 0; i < TPW; i++) {
             const int nt = min(wave + 4 * i, ntile - 1);   // clamp: surplus tiles recompute the last one
-#pragma unroll
-            for (int u = 0; u < 8; u++) bw[buf][i][u] = wfc_pk[((size_t)nt * KS + s0 + u) * 64 + lane];
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wfc_pk) + (((size_t)nt * KG + g) * 64 + lane) * 2;
+            bw[buf][i][0] = wp[0];
+            bw[buf][i][1] = wp[1];
         }
     };
-    if (KS >= 8) load_trip(0, 0);
-    for (; s + 16 <= KS; s += 16) {              // two trips per iteration: static buffer indices
-        float a[8];
-        load_trip(s + 8, 1);
-#pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + u)];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-#pragma unroll
-            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[0][i][u], acc[i], 0, 0, 0);
-        if (s + 24 <= KS) load_trip(s + 16, 0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + 8 + u)];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-#pragma unroll
-            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[1][i][u], acc[i], 0, 0, 0);
-    }
-    if (s + 8 <= KS) {                           // one trip left (its fragments are in buffer 0)
+    auto mma_trip = [&](int g, int buf) {
         float a[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = arow[4 * (s + u)];
+        for (int u = 0; u < 8; u++) a[u] = arow[4 * min(8 * g + u, KS - 1)];   // past KS: any valid step (weights are 0)
 #pragma unroll
         for (int u = 0; u < 8; u++)
 #pragma unroll
-            for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[0][i][u], acc[i], 0, 0, 0);
-        s += 8;
+            for (int i = 0; i < TPW; i++)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[buf][i][u >> 2][u & 3], acc[i], 0, 0, 0);
+    };
+    load_trip(0, 0);
+    int g = 0;
+    for (; g + 2 <= KG; g += 2) {               // two trips per iteration: static buffer indices
+        load_trip(g + 1, 1);
+        mma_trip(g, 0);
+        if (g + 2 < KG) load_trip(g + 2, 0);
+        mma_trip(g + 1, 1);
     }
-    for (; s < KS; s++) {
-        const float a = arow[4 * s];
-#pragma unroll
-        for (int i = 0; i < TPW; i++) {
-            const int nt = min(wave + 4 * i, ntile - 1);
-            const float bw = wfc_pk[((size_t)nt * KS + s) * 64 + lane];
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[i], 0, 0, 0);
-        }
-    }
+    if (g < KG) mma_trip(g, 0);                 // odd trip count: its fragments are in buffer 0
     __syncthreads();            // features consumed; reuse LDS for the logits
     float* lg = sm;
 #pragma unroll
