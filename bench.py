@@ -60,9 +60,8 @@ def load_mean_plies():
     return None, None
 
 
-def cpu_baseline(mean_plies, budget_s=15.0):
-    """Sequential oracle (scalar tree, one batch-1 forward per playout) on ONE host core."""
-    import random
+def _cpu_worker(budget_s):
+    """One sequential self-play search loop on one core: oracle tree + oracle/net_ref.c batch-1 forward per playout."""
     from oracle.board_ref import RefBoard
     from oracle.mcts_ref import RefMCTS
     from oracle.net_ref_c import CNet
@@ -76,12 +75,34 @@ def cpu_baseline(mean_plies, budget_s=15.0):
     while time.perf_counter() - t0 < budget_s:
         mcts.playout(b.clone())
         n += 1
-    dt = time.perf_counter() - t0
-    leaf_s = n / dt
-    return {"value": leaf_s / (N_PLAYOUT * mean_plies), "unit": "games/s", "cores": 1, "kind": "port",
-            "leaf_evals_per_s": leaf_s,
-            "sample": "%d sequential playouts of one 15x15 game (oracle tree + oracle/net_ref.c batch-1 forward), "
-                      "%.1f s on 1 core; games/s = leaf-evals/s / (400 * mean plies)" % (n, dt)}
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(mean_plies, cores, budget_s=15.0):
+    """The sequential oracle (scalar tree, one batch-1 forward per playout) as `cores` independent self-play
+    workers, one process per host core (child processes: this one has the GPU open), ~15 s each."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO) for _ in range(cores)]
+    total_n, rates = 0, []
+    for p in procs:
+        out, _ = p.communicate()
+        try:
+            r = json.loads(out.decode().strip().splitlines()[-1])
+            total_n += r["n"]
+            rates.append(r["n"] / r["dt"])
+        except (ValueError, IndexError, KeyError):
+            pass
+    if not rates:                      # no child came back: measure in-process on one core
+        n, dt = _cpu_worker(budget_s)
+        total_n, rates = n, [n / dt]
+    leaf_s = sum(rates)
+    return {"value": leaf_s / (N_PLAYOUT * mean_plies), "unit": "games/s", "cores": len(rates), "kind": "port",
+            "leaf_evals_per_s": leaf_s, "leaf_evals_per_s_per_core": leaf_s / len(rates),
+            "sample": "%d sequential playouts in %d independent 15x15 self-play searches, one process per core (oracle tree + "
+                      "oracle/net_ref.c batch-1 forward), %.0f s each; games/s = leaf-evals/s / (400 * mean plies)"
+                      % (total_n, len(rates), budget_s)}
 
 
 def stem_roofline(device):
@@ -117,12 +138,17 @@ def main():
     ap.add_argument("--full-games", type=int, default=0, help="play this many COMPLETE games per GPU "
                     "instead of timing --steps (measures games/s and mean plies directly; minutes)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # child of cpu_baseline()
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (gloo, stand-in evaluator from tests/fakenet.py, "
                          "8 games per rank); the JSON line is marked invalid and is NOT a measurement")
     args = ap.parse_args()
+    if args.cpu_worker > 0:
+        n_, dt_ = _cpu_worker(args.cpu_worker)
+        print(json.dumps({"n": n_, "dt": dt_}))
+        return
 
     rank, world, local = dist.init(backend="gloo" if args.plumbing_test else None)
     if world != args.gpus and world > 1:
@@ -312,7 +338,7 @@ def main():
         line["data"] = "plumbing-test (CPU stand-in evaluator, 8 games per rank): NOT a measurement"
     if not args.no_extras and world == 1 and not args.plumbing_test:
         line["roofline_stem"] = stem_roofline(local)
-        line["cpu_baseline"] = cpu_baseline(mean_plies)
+        line["cpu_baseline"] = cpu_baseline(mean_plies, cores=max(1, min(16, ncpu)))
     print(json.dumps(line))
 
 
