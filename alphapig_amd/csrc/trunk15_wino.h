@@ -8,7 +8,7 @@
 // tile)   M[pos][co][tile] = sum_ci U[pos][co][ci] * V[pos][ci][tile]
 // = 36 x 8 co-tiles x 32 k-steps = 9216 v_mfma_f32_16x16x4_f32 per board instead of 34560
 // (3.75x fewer).  fp32 error of the whole 20-layer trunk stays ~1e-5 on the logits (measured:
-// tools/winograd_numerics.py; tolerance of the path is 1e-4).
+// tests/winograd_numerics.py; tolerance of the path is 1e-4).
 //
 // One workgroup (8 waves, two per SIMD) owns a board at a time and keeps ALL of its
 // 36 x 128 x 16 accumulators in registers (wave w: output channels 16w..16w+15, 144 accumulator

@@ -5,7 +5,8 @@
             (python restatement of mcts_pure.py) vs the native host library, same seeds
   config 2  8x8, 4-in-row, n_playout=200, simple net, 64 concurrent games on the GPU
   config 3  15x15, 5-in-row, n_playout=400, 10-block residual net, 1024 concurrent games (short slice)
-Prints one JSON object.  Run on the GPU box:  python tools/config_table.py
+Prints one JSON object.  Run on the GPU box:  python tests/config_table.py
+(Lives under tests/: config 1 times the CPU oracle, which only tests, smoke() and bench.py's cpu_baseline may import.)
 """
 import json
 import os

@@ -1,4 +1,5 @@
-"""fp32 error of F(2x2,3x3) / F(4x4,3x3) Winograd trunk convolutions over the whole 20-layer residual
+"""(Lives under tests/: it uses the CPU oracle, which only tests, smoke() and the cpu_baseline of bench.py may import.)
+fp32 error of F(2x2,3x3) / F(4x4,3x3) Winograd trunk convolutions over the whole 20-layer residual
 net, against the float64 oracle (CPU, numpy): the evidence behind trunk15_wino.h staying inside
 the 1e-4 logit tolerance.  Uses oracle/ (test infrastructure) -- a tool, not part of the product path."""
 import sys, numpy as np
