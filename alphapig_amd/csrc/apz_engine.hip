@@ -1252,8 +1252,10 @@ int apz_adam_step(apz_engine* e, const void* table_host, int ntensors, float lr_
         HIP_TRY(hipMalloc((void**)&e->adam_tab, bytes));
         e->adam_cap = bytes;
     }
-    // pageable source: the copy is staged by the runtime before this call returns, and ordered on the stream
-    HIP_TRY(hipMemcpyAsync(e->adam_tab, table_host, bytes, hipMemcpyHostToDevice, e->stream));
+    // the table buffer of the previous step may still be read by its kernel: wait for it, then a SYNCHRONOUS copy (the
+    // caller's host buffer need not outlive this call; 6 KB)
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->adam_tab, table_host, bytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(apz::adam_step_kernel, dim3(32, ntensors), dim3(256), 0, e->stream,
                        (const apz::AdamTensor*)e->adam_tab, lr_t, b1, b2, eps, rescale);
     HIP_TRY(hipGetLastError());
