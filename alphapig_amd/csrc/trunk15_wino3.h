@@ -1,0 +1,487 @@
+// Trunk 3x3 convolution (128 -> 128 channels, 15x15 board) + folded BN + (residual) + ReLU as a
+// fused F(4x4,3x3) Winograd convolution on the fp32 matrix cores -- SINGLE PASS: a work item is
+// two boards x 64 output channels with all 36 transformed positions.  gfx950 only.
+// Successor of trunk15_wino2.h (same math, same HBM layouts, same packed weights `upk2`).
+//
+// Why (round-2 measurements of trunk15_wino2_kernel, profiles/r01_trunk_winograd.md): two boards x 128
+// channels x 36 positions of accumulators (590 KB) do not fit the 512 KB register file, so wino2 made
+// two passes over the input (18 positions each), parked pass 0's partial outputs in `out` and re-read
+// them: 2.5x the direct-convolution HBM/fabric traffic, two epilogues (25 % of the launch) and an
+// input transform run by one wave per SIMD against the other's MFMA stream (16 %).
+// Here the accumulator budget is spent the other way round: 2 boards x 64 channels x 36 positions
+// (295 KB) -- a weight fragment still feeds two MFMAs, nothing is parked, every output is written
+// once, the input is read once per channel half (2x, as before), and all eight waves do the same
+// thing in every chunk.  Price: the input transform runs once per channel half (2x the VALU work of
+// wino2); it is spread over all 512 threads (half a 6x6 tile each) and sits inside each wave's own
+// MFMA stream, where a VALU instruction costs ~4 cycles instead of one MFMA slot (tools/mfma_valu_probe).
+//
+// Work item t of a workgroup = (board pair t>>1, channel half h = t&1).  Wave w: ct = w&3 (16 output
+// channels cot*16.., cot = 4h + ct), ph = w>>2 (transformed rows 3ph..3ph+2 = 18 positions), both
+// boards: 2 x 18 x 4 = 144 accumulator registers.  Per item the 128 input channels stream through in
+// 16 chunks of 8, one barrier per chunk:
+//   iteration g: [barrier] raw(g+2) regs -> LDS; issue loads raw(g+3);
+//                transform raw(g+1) -> V[(g+1)&1] (thread = (board, channel, tile) x row half);
+//                72 MFMAs over V[g&1]; weight ring (5 x 16 B per lane) refilled one k-step ahead.
+// Epilogue of an item: wave (ct, ph) holds rows 3ph..3ph+2 of M; Y = A^T M A needs all six, so the
+// two waves of a channel tile swap 12 values per (channel, tile) through LDS (X) -- wave ph sends its
+// row-partial of board 1-ph and finishes board ph: + bias (+ residual), ReLU, whole-plane stores
+// through the wave-private staging area (as wino2).
+//
+// Layouts.  in / resid / out: rows16 [n][128][15][16] (col 15 == 0), as trunk15_ring.h.
+// upk: [cot 8][ph 2][c4 32][lane 64][20] (Wino2's): lane (q = lane>>4, j = lane&15) holds
+//      U[row 3*ph + ii][k] at index 6*ii + k of co = cot*16 + j, ci = c4*4 + q.
+// raw (LDS): as wino2 ([2 boards x 8 channels] planes, row stride 20, plane stride 340, zero halo).
+// V (LDS): [pp 18][board 2][ch 8][tile 16][2]: pp = position pair (row i, columns 2kp, 2kp+1) = 3i + kp;
+//      the B operands of positions 2pp, 2pp+1 are one conflict-free ds_read_b64, no padding.
+// X (LDS, inside V[1], which is idle during an epilogue): [wave 8][3][lane 64][4].
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "trunk15_wino2.h"
+
+namespace apz {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Wino3 {
+    static constexpr int C = 128, CK = 8, NCHUNK = C / CK;            // 16 iterations per item
+    static constexpr int GPLANE = 240;                 // floats per plane in HBM (15 rows x 16)
+    static constexpr int RROW = 20, RPS = 17 * RROW;   // LDS row / plane stride
+    static constexpr int RFRONT = 24;
+    static constexpr int RAW_FLOATS = RFRONT + 2 * CK * RPS;          // 5464
+    static constexpr int VPP = 2 * CK * 16 * 2;        // floats per position pair: 256 units x 2
+    static constexpr int V_FLOATS = 18 * VPP;          // 9216 (36 KiB)
+    static constexpr int XW = 3 * 64 * 4;              // exchange floats per wave
+    static constexpr int SROW = 20, SPLANE = 16 * SROW;               // epilogue staging: 16 rows x 20 floats per plane
+    static constexpr int STAGE_FLOATS = 8 * 4 * SPLANE;               // 8 waves x 4 planes (40 KiB)
+    static constexpr int LDS_FLOATS = 2 * RAW_FLOATS + 2 * V_FLOATS + STAGE_FLOATS;   // 39600 floats = 154.7 KiB
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int UROW = 20;                    // floats per lane and k-step in upk
+    static constexpr int USTEP = 64 * UROW;            // floats per k-step of one (cot, ph)
+    static_assert(8 * XW <= V_FLOATS, "X lives inside V[1]");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+#ifdef APZ3_EPI_WAIT
+#define APZ3_FENCE()                                  \
+    {                                                 \
+        __builtin_amdgcn_s_waitcnt(0xc07f);           \
+        wave_lds_fence();                             \
+    }
+#else
+#define APZ3_FENCE() wave_lds_fence()
+#endif
+
+#ifdef APZ3_DEBUG_X
+__device__ float apz_wino3_dbg[8 * 4 * 2 * 64 * 4];   // [wave][r][sent/received][lane][4]: P2 of the exchange
+#endif
+#ifdef APZ_WINO3_STAMPS
+// cycle accounting (tools/wino_ablate.hip): [workgroup 4][wave 8][phase 8], read with hipMemcpyFromSymbol
+__device__ unsigned long long apz_wino3_stamps[4 * 8 * 8];
+#endif
+
+// RELU = false: the plain convolution + bias (training graph: forward before BatchNorm, data gradient)
+template <bool RESID, bool RELU = true>
+__global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restrict__ in, const float* __restrict__ upk,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ resid, float* __restrict__ out,
+                                                            int n) {
+    using T = Wino3;
+#ifdef APZ_WINO3_STAMPS
+    // phases: 0 prologue, 1 barrier wait, 2 chunk body (staging + transform + MFMA), 3 epilogue, 7 total
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_readcyclecounter();
+    const unsigned long long st_t0 = st_t;
+#define APZ3_STAMP(ph_)                                               \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        st_acc[ph_] += now_ - st_t;                                   \
+        st_t = now_;                                                  \
+    }
+#else
+#define APZ3_STAMP(ph_)
+#endif
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* rawb = lds;                                        // [2][RAW_FLOATS]
+    float* vb = lds + 2 * T::RAW_FLOATS;                      // [2][V_FLOATS]
+    float* stg = lds + 2 * T::RAW_FLOATS + 2 * T::V_FLOATS;   // [8 waves][4 planes][16 rows x 20]
+    float* xb = vb + T::V_FLOATS;                             // X: inside V[1] (free between an item's last MFMA and the next item's first transform)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, j = lane & 15;
+    const int ct = wave & 3;
+
+    for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 2048) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef APZ3_POISON
+    for (int i = tid; i < T::STAGE_FLOATS; i += 512) stg[i] = 777.f;
+#endif
+
+    const int npairs = (n + 1) >> 1;
+    const int np = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // board pairs of this workgroup
+    const int nitems = 2 * np;
+    const int total_iters = nitems * T::NCHUNK;
+    if (np == 0) return;                        // (launchers never oversubscribe; uniform, before any barrier)
+
+    // All global memory traffic goes through raw buffer instructions: descriptor (SGPRs) + per-lane 32-bit offset
+    // + wave-uniform SGPR offset.  No 64-bit per-lane addresses (registers, VALU), and lanes that must not take
+    // part (60..63 of a 960-byte plane) get an offset beyond the buffer: their loads return 0, their stores are dropped.
+    const unsigned plane_b = T::GPLANE * 4;                    // 960
+    const unsigned act_bytes = (unsigned)n * T::C * plane_b;   // launchers keep this below 2^31
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESID ? resid : in), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_u =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(upk), 0, (unsigned)(Wino2::UPK_FLOATS * 4), 0x00020000);
+    auto bload = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    // Stores keep soffset = 0 and add the uniform part into the per-lane offset.  With an SGPR soffset hipcc (ROCm 7.2)
+    // emits no wait state between a 128-bit buffer store and a VALU write of its data registers (LLVM's hazard
+    // recognizer exempts that form), and on gfx950 the store then picks up the NEW value of the last dword in some
+    // lanes (found the hard way: one element per 4x4 tile of every 16th channel wrong, and only in some builds).
+    auto bstore = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, const f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, 0);
+    };
+
+    // ---- staging roles: 2 boards x 8 planes x 60 pieces of 16 B; 32 threads per plane, two pieces each (four of them
+    // twice).  thread -> plane tid>>5: board = tid>>8 (wave-uniform: waves 0..3 stage board 0), channel (tid>>5)&7.
+    // Every thread issues exactly two loads and two LDS stores per iteration, unconditionally (exact vmcnt counting).
+    const int st_k = tid & 31, st_k2 = (st_k + 32 < 60) ? st_k + 32 : st_k;
+    const unsigned st_vo = ((tid >> 5) & 7) * plane_b + st_k * 16, st_vo2 = ((tid >> 5) & 7) * plane_b + st_k2 * 16;
+    f32x4 rg[2];
+    auto raw_fetch = [&](int g) {               // global -> registers (iteration g of this workgroup's stream, clamped)
+        g = g < total_iters ? g : total_iters - 1;
+        const int bdp = 2 * ((int)blockIdx.x + (g / (2 * T::NCHUNK)) * (int)gridDim.x) + (wave >> 2), c = g & (T::NCHUNK - 1);
+        const int bd = bdp < n ? bdp : n - 1;
+        const unsigned so = (unsigned)(bd * T::C + c * T::CK) * plane_b;
+        rg[0] = bload(r_in, st_vo, so);
+        rg[1] = bload(r_in, st_vo2, so);
+    };
+    auto raw_store = [&](int g) {               // registers -> raw LDS buffer g&1
+        float* dst = rawb + (g & 1) * T::RAW_FLOATS + T::RFRONT + (tid >> 5) * T::RPS;
+        *reinterpret_cast<f32x4*>(dst + (st_k >> 2) * T::RROW + (st_k & 3) * 4) = rg[0];
+        *reinterpret_cast<f32x4*>(dst + (st_k2 >> 2) * T::RROW + (st_k2 & 3) * 4) = rg[1];
+    };
+    // Everything below is instantiated twice, for ph = 0 and ph = 1 (wave-uniform branch at the bottom): the row
+    // half decides transform formulas and epilogue register indices, and a branch inside the chunk body would cut
+    // the basic block the scheduler interleaves the transform's VALU work with the MFMAs in.
+    auto run = [&](auto PH) {
+    constexpr int ph = decltype(PH)::value;
+    // ---- transform roles: thread = unit (board, channel, tile) x row half (tid>>8 == ph: rows 3ph..3ph+2)
+    const int unit = tid & 255;
+    const int tty = (unit >> 2) & 3, ttx = unit & 3;
+    const int tr_off = T::RFRONT + (unit >> 4) * T::RPS + (4 * tty - 1 + ph) * T::RROW + 4 * ttx;   // HI half skips patch row 0
+    const int tv_off = (9 * ph) * T::VPP + unit * 2;
+    // The transform of one chunk is cut into 18 slices (one per MFMA slot of the chunk body, see below); all of its
+    // temporaries are named here so that a slice can pick up where the previous one stopped.
+    //   slices 0..2: LDS reads of the five patch rows, as column pairs that need no register moves:
+    //                xr[i][0] = (col -1, col 4) (one ds_read2_b32), xr[i][1] = (col 0, col 1), xr[i][2] = (col 2, col 3);
+    //   slices 2..7: B^T over the rows, row by row as they arrive (elementwise in the columns):
+    //                ph 0: y0 = 4x0 - 5x2 + x4, y1 = a + b, y2 = a - b with a = x4 - 4x2, b = x3 - 4x1   (x = patch rows 0..4)
+    //                ph 1: y3 = c + 2d, y4 = c - 2d with c = z3 - z1, d = z2 - z0, y5 = 4z0 - 5z2 + z4  (z = patch rows 1..5)
+    //   slices 8..16: B^T over the columns of each of the three rows (wino2_bt6's formulas), three slices per row,
+    //                the row's three ds_write_b64 in its last slice.
+    f32x2 xr[5][3], u0[3], u1[3], u2[3], tt[3][3];
+    float o14[4];
+    auto tslice = [&](int g, auto KK) {         // raw[g&1] -> V[g&1], rows 3ph .. 3ph+2; slice KK of 18
+        constexpr int K = decltype(KK)::value;
+        const float* rp = rawb + (g & 1) * T::RAW_FLOATS + tr_off;
+        float* vp = vb + (g & 1) * T::V_FLOATS + tv_off;
+        auto load_row = [&](int i) {
+            xr[i][0] = f32x2{rp[i * T::RROW - 1], rp[i * T::RROW + 4]};
+            const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
+            xr[i][1] = f32x2{c03[0], c03[1]};
+            xr[i][2] = f32x2{c03[2], c03[3]};
+        };
+        if constexpr (K == 0) {
+            load_row(0);
+            load_row(1);
+        } else if constexpr (K == 1) {
+            load_row(2);
+            load_row(3);
+        } else if constexpr (K == 2) {
+            load_row(4);
+#pragma unroll
+            for (int cp = 0; cp < 3; cp++) {
+                u0[cp] = 4.f * xr[0][cp];
+                if (ph == 1) u2[cp] = -xr[0][cp];
+            }
+        } else if constexpr (K == 3) {
+#pragma unroll
+            for (int cp = 0; cp < 3; cp++) {
+                if (ph == 0)
+                    u2[cp] = -4.f * xr[1][cp];
+                else
+                    u1[cp] = -xr[1][cp];
+            }
+        } else if constexpr (K == 4) {
+#pragma unroll
+            for (int cp = 0; cp < 3; cp++) {
+                u0[cp] = fma2(-5.f, xr[2][cp], u0[cp]);
+                if (ph == 0)
+                    u1[cp] = -4.f * xr[2][cp];
+                else
+                    u2[cp] = u2[cp] + xr[2][cp];
+            }
+        } else if constexpr (K == 5) {
+#pragma unroll
+            for (int cp = 0; cp < 3; cp++) {
+                if (ph == 0)
+                    u2[cp] = u2[cp] + xr[3][cp];
+                else
+                    u1[cp] = u1[cp] + xr[3][cp];
+            }
+        } else if constexpr (K == 6) {
+#pragma unroll
+            for (int cp = 0; cp < 3; cp++) {
+                u0[cp] = u0[cp] + xr[4][cp];
+                if (ph == 0) u1[cp] = u1[cp] + xr[4][cp];
+            }
+        } else if constexpr (K == 7) {
+#pragma unroll
+            for (int cp = 0; cp < 3; cp++) {
+                if (ph == 0) {
+                    tt[0][cp] = u0[cp];
+                    tt[1][cp] = u1[cp] + u2[cp];
+                    tt[2][cp] = u1[cp] - u2[cp];
+                } else {
+                    tt[0][cp] = fma2(2.f, u2[cp], u1[cp]);
+                    tt[1][cp] = fma2(-2.f, u2[cp], u1[cp]);
+                    tt[2][cp] = u0[cp];
+                }
+            }
+        } else if constexpr (K >= 8 && K <= 16) {
+            constexpr int ii = (K - 8) / 3, part = (K - 8) % 3;
+            const float v0 = tt[ii][0][0], v5 = tt[ii][0][1], v1 = tt[ii][1][0], v2 = tt[ii][1][1], v3 = tt[ii][2][0],
+                        v4 = tt[ii][2][1];
+            if constexpr (part == 0) {
+                const float a = __builtin_fmaf(-4.f, v2, v4), b = __builtin_fmaf(-4.f, v1, v3);
+                o14[0] = a + b;
+                o14[1] = a - b;
+            } else if constexpr (part == 1) {
+                const float c = v4 - v2, d = v3 - v1;
+                o14[2] = __builtin_fmaf(2.f, d, c);
+                o14[3] = __builtin_fmaf(-2.f, d, c);
+            } else {
+                const float o0 = __builtin_fmaf(4.f, v0, __builtin_fmaf(-5.f, v2, v4));
+                const float o5 = __builtin_fmaf(4.f, v1, __builtin_fmaf(-5.f, v3, v5));
+                *reinterpret_cast<f32x2*>(vp + (ii * 3 + 0) * T::VPP) = f32x2{o0, o14[0]};
+                *reinterpret_cast<f32x2*>(vp + (ii * 3 + 1) * T::VPP) = f32x2{o14[1], o14[2]};
+                *reinterpret_cast<f32x2*>(vp + (ii * 3 + 2) * T::VPP) = f32x2{o14[3], o5};
+            }
+        }
+    };
+#define APZ3_ALL18(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17)
+    auto transform = [&](int g) {               // the whole transform at once (prologue)
+#define APZ3_TS(k) tslice(g, std::integral_constant<int, k>{});
+        APZ3_ALL18(APZ3_TS)
+#undef APZ3_TS
+    };
+
+    // ---- weight stream of this wave: k-step (item half h, c4) -> five f32x4 per lane; ring = one k-step,
+    // piece v refilled right after its last MFMA with the same piece of the next k-step (28 MFMAs ahead).
+    const unsigned ulane = lane * (T::UROW * 4);
+    auto uload = [&](int ks, int v) {           // ks = global k-step of this workgroup's stream (32 per item), v = piece 0..4
+        const int hh = (ks >> 5) & 1, kk = ks & 31;
+        const unsigned so = (unsigned)(((hh * 4 + ct) * 2 + ph) * 32 + kk) * (T::USTEP * 4);
+        if (v == 4) {                           // values 16, 17 (+ 2 pad floats that are never loaded: dead registers under an
+            const auto w = __builtin_amdgcn_raw_buffer_load_b64(r_u, ulane + 64, so, 0);   // in-flight load get reused -> WAW waits)
+            const f32x2 f = __builtin_bit_cast(f32x2, w);
+            return f32x4{f[0], f[1], 0.f, 0.f};
+        }
+        return bload(r_u, ulane + v * 16, so);
+    };
+    f32x4 ur[5];
+    {
+        raw_fetch(0);
+        const f32x4 r0 = rg[0], r1 = rg[1];
+        raw_fetch(1);
+        __syncthreads();                        // zero fill done
+        raw_store(1);
+        rg[0] = r0;
+        rg[1] = r1;
+        raw_store(0);
+    }
+    __syncthreads();
+    transform(0);
+    raw_fetch(2);
+    // the first weights AFTER the staging loads: at the top of the chunk loop the staging registers are waited for
+    // with vmcnt(N), N = the loads issued after them -- N is the minimum over the paths into the loop, and this
+    // path must not make it 0 (a full drain of the weight ring at every chunk)
+#pragma unroll
+    for (int v = 0; v < 5; v++) ur[v] = uload(0, v);
+    APZ3_STAMP(0)
+
+    const int ety = j >> 2, etx = j & 3;
+    float* sw = stg + wave * (4 * T::SPLANE);
+    const int s_own = q * T::SPLANE + (4 * ety) * T::SROW + 4 * etx;        // this lane's 4x4 patch (row a: + a*SROW)
+    const int s_lin = (lane >> 2) * T::SROW + (lane & 3) * 4;               // plane piece `lane` (row lane>>2, quarter lane&3)
+    float* xw_own = xb + wave * T::XW + lane * 4;
+    const float* xw_oth = xb + (wave ^ 4) * T::XW + lane * 4;
+
+    for (int t = 0; t < nitems; t++) {
+        const int h = t & 1;
+        const int bd0 = 2 * ((int)blockIdx.x + (t >> 1) * (int)gridDim.x);
+        const bool two = bd0 + 1 < n;           // the last pair of an odd batch has one board (computed twice, stored once)
+        f32x4 acc[2][18];
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int p = 0; p < 18; p++) acc[b][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < T::NCHUNK; c++) {
+            const int g = t * T::NCHUNK + c;
+            __syncthreads();                    // V[g&1] complete, V[(g+1)&1] and raw[g&1] free, raw[(g+1)&1] visible
+            APZ3_STAMP(1)
+            // 18 slots of 4 MFMAs (k-step s = slot / 9, position pair m = slot % 9, both boards).  A slot reads the B
+            // operands of the NEXT slot, issues its MFMAs, runs one slice of the transform of chunk g+1 and, when a
+            // weight piece has seen its last MFMA, refills it for the next k-step.  sched_barrier(0) pins the slots:
+            // left alone, hipcc clusters the transform in front of the MFMAs and sinks the weight loads to their use.
+            const float* vp = vb + (g & 1) * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+            f32x2 bc0 = *reinterpret_cast<const f32x2*>(vp), bc1 = *reinterpret_cast<const f32x2*>(vp + 256);
+#define APZ3_SLOT(k)                                                                                               \
+            {                                                                                                      \
+                constexpr int s = (k) / 9, m = (k) % 9, sn = ((k) + 1) / 9, mn = ((k) + 1) % 9;                        \
+                f32x2 bn0 = bc0, bn1 = bc1;                                                                        \
+                if ((k) + 1 < 18) {                                                                                \
+                    bn0 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + sn * 128);                            \
+                    bn1 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + 256 + sn * 128);                      \
+                }                                                                                                  \
+                const float a0 = ur[m >> 1][(2 * m) & 3], a1 = ur[m >> 1][(2 * m + 1) & 3];                        \
+                acc[0][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc0[0], acc[0][2 * m], 0, 0, 0);          \
+                acc[1][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc1[0], acc[1][2 * m], 0, 0, 0);          \
+                acc[0][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc0[1], acc[0][2 * m + 1], 0, 0, 0);  \
+                acc[1][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc1[1], acc[1][2 * m + 1], 0, 0, 0);  \
+                if ((k) == 0) raw_store(g + 2);                                                                    \
+                if ((k) == 1) raw_fetch(g + 3);                                                                    \
+                tslice(g + 1, std::integral_constant<int, (k)>{});                                                 \
+                if ((m & 1) || m == 8) ur[m >> 1] = uload(2 * g + s + 1, m >> 1);                                  \
+                bc0 = bn0;                                                                                         \
+                bc1 = bn1;                                                                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+            }
+            APZ3_ALL18(APZ3_SLOT)
+#undef APZ3_SLOT
+            APZ3_STAMP(2)
+        }
+
+        // ---- epilogue of the item.  Lane (q, j): tile j = 4*ety + etx, channels cot*16 + 4q + r.
+        // h_i = the k-direction transform of row i (wino2_at6).  With lo = (h0+h1+h2, h1-h2, h1+h2) from the ph = 0
+        // wave and hi = (h3+h4, h3-h4, h5) from the ph = 1 wave:
+        //   y0 = lo0 + hi0;  y1 = lo1 + 2 hi1;  y2 = lo2 + 4 hi0;  y3 = lo1 + 8 hi1 + hi2.
+        // Wave ph finishes board ph and sends its partial of board 1-ph.  No divergence: every wave runs the same
+        // barriers; the missing second board of an odd batch's last pair is computed from a copy of the first and
+        // never stored.
+        const int cot = 4 * h + ct;
+        const int bd_own = (ph == 0 || !two) ? bd0 : bd0 + 1;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cot * 16 + q * 4);
+        const unsigned ep_vo = lane < 60 ? lane * 16 : 0x80000000u;             // piece `lane` of a plane; lanes 60..63 out of range
+        const unsigned st_out_vo = ((ph == 0) || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch: stores dropped
+        auto plane_so = [&](int r, int qp) {                                    // plane q' of step r
+            return (unsigned)__builtin_amdgcn_readfirstlane(bd_own * T::C + cot * 16 + qp * 4 + r) * plane_b;
+        };
+        auto partial = [&](const f32x4* a, int r, f32x4* p) {   // rows of this wave -> (P0, P1, P2)
+            float hh[3][4];
+#pragma unroll
+            for (int ii = 0; ii < 3; ii++)
+                wino2_at6(a[ii * 6 + 0][r], a[ii * 6 + 1][r], a[ii * 6 + 2][r], a[ii * 6 + 3][r], a[ii * 6 + 4][r],
+                          a[ii * 6 + 5][r], hh[ii]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (ph == 0) {
+                    const float s12 = hh[1][e] + hh[2][e];
+                    p[0][e] = hh[0][e] + s12;
+                    p[1][e] = hh[1][e] - hh[2][e];
+                    p[2][e] = s12;
+                } else {
+                    p[0][e] = hh[0][e] + hh[1][e];
+                    p[1][e] = hh[0][e] - hh[1][e];
+                    p[2][e] = hh[2][e];
+                }
+            }
+        };
+        {
+            constexpr int own = ph;             // static register indices
+            f32x4 win[4];
+            auto resid_load = [&](int r) {
+#pragma unroll
+                for (int qp = 0; qp < 4; qp++) win[qp] = bload(r_res, ep_vo, plane_so(r, qp));
+            };
+            if (RESID) resid_load(0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                f32x4 ps[3];
+                partial(acc[1 - own], r, ps);
+                __syncthreads();                // r = 0: every wave's MFMAs over V[1] are done; r > 0: X of step r-1 consumed
+#pragma unroll
+                for (int v = 0; v < 3; v++) *reinterpret_cast<f32x4*>(xw_own + v * 256) = ps[v];
+#ifdef APZ3_DEBUG_X
+                if (blockIdx.x == 0 && t == 0)
+                    *reinterpret_cast<f32x4*>(&apz_wino3_dbg[(((wave * 4 + r) * 2 + 0) * 64 + lane) * 4]) = ps[2];
+#endif
+                f32x4 po[3];
+                partial(acc[own], r, po);
+                f32x4 w4[4];
+                if (RESID) {                    // plane pieces -> staging -> this lane's 4x4 patch
+#pragma unroll
+                    for (int qp = 0; qp < 4; qp++) *reinterpret_cast<f32x4*>(sw + qp * T::SPLANE + s_lin) = win[qp];   // (lanes 60..63: row 15, unused)
+                    APZ3_FENCE();
+#pragma unroll
+                    for (int a = 0; a < 4; a++) w4[a] = *reinterpret_cast<const f32x4*>(sw + s_own + a * T::SROW);
+                    APZ3_FENCE();
+                    if (r + 1 < 4) resid_load(r + 1);
+                }
+                __syncthreads();                // X of step r complete
+                f32x4 px[3];
+#pragma unroll
+                for (int v = 0; v < 3; v++) px[v] = *reinterpret_cast<const f32x4*>(xw_oth + v * 256);
+#ifdef APZ3_DEBUG_X
+                if (blockIdx.x == 0 && t == 0)
+                    *reinterpret_cast<f32x4*>(&apz_wino3_dbg[(((wave * 4 + r) * 2 + 1) * 64 + lane) * 4]) = px[2];
+#endif
+                const f32x4* lo = own == 0 ? po : px;
+                const f32x4* hi = own == 0 ? px : po;
+                f32x4 y[4];
+                y[0] = lo[0] + hi[0];
+                y[1] = lo[1] + 2.f * hi[1];
+                y[2] = lo[2] + 4.f * hi[0];
+                y[3] = lo[1] + (8.f * hi[1] + hi[2]);
+                const float bvr = bv[r];
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    f32x4 v = y[a] + bvr;
+                    if (RESID) v += w4[a];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) y[a][e] = RELU ? fmaxf(v[e], 0.f) : v[e];
+                    if (etx == 3) y[a][3] = 0.f;   // column 15 is the halo column of the rows16 layout
+                    *reinterpret_cast<f32x4*>(sw + s_own + a * T::SROW) = y[a];   // (row 15 of tile row 3 lands in the pad row)
+                }
+                APZ3_FENCE();
+                f32x4 pv[4];
+#pragma unroll
+                for (int qp = 0; qp < 4; qp++) pv[qp] = *reinterpret_cast<const f32x4*>(sw + qp * T::SPLANE + s_lin);
+                APZ3_FENCE();
+#pragma unroll
+                for (int qp = 0; qp < 4; qp++)
+                    bstore(r_out, st_out_vo, plane_so(r, qp), pv[qp]);
+            }
+        }
+        APZ3_STAMP(3)
+    }
+    };
+    if ((wave >> 2) == 0)
+        run(std::integral_constant<int, 0>{});
+    else
+        run(std::integral_constant<int, 1>{});
+#ifdef APZ_WINO3_STAMPS
+    st_acc[7] = __builtin_readcyclecounter() - st_t0;
+    if (lane == 0 && blockIdx.x < 4)
+        for (int i = 0; i < 8; i++) apz_wino3_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_acc[i];
+#endif
+}
+
+}  // namespace apz
