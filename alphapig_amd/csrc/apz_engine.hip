@@ -19,6 +19,7 @@
 #include "trunk15_ring.h"
 #include "trunk15_wino.h"
 #include "trunk15_wino2.h"
+#include "trunk15_wino3.h"
 #include "wgrad_wino.h"
 #include "sampler.h"
 #include "conv_train.h"
@@ -114,8 +115,8 @@ struct apz_engine {
     float* wino_scratch[2] = {nullptr, nullptr};   // apz_wino_conv: rows16 input / output copies
     size_t wino_scratch_boards = 0;
     bool wgrad_attr_set[2] = {false, false};
-    int trunk_kernel = 2;   // 0: trunk15_ring_kernel (direct), 1: trunk15_wino_kernel, 2: trunk15_wino2_kernel
-                            // (APZ_TRUNK_KERNEL=ring|wino|wino2)
+    int trunk_kernel = 3;   // 0: trunk15_ring_kernel (direct), 1: trunk15_wino_kernel, 2: trunk15_wino2_kernel,
+                            // 3: trunk15_wino3_kernel (APZ_TRUNK_KERNEL=ring|wino|wino2|wino3)
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
     // profiling
     bool profiling = false;
@@ -353,8 +354,31 @@ int launch_trunk_wino2(apz_engine* e, const ConvLayer& L, const float* in, const
     return APZ_OK;
 }
 
+int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Wino3;
+    bool& configured = e->lds_attr_set[6];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        configured = true;
+    }
+    const int grid = std::min((n + 1) / 2, e->num_cu);   // one persistent workgroup per CU; item = board pair x channel half
+    if (resid)
+        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
+                           L.bias, resid, out, n);
+    else
+        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
+                           L.bias, resid, out, n);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    if (e->trunk_kernel == 2 && L.upk2) return launch_trunk_wino2(e, L, in, resid, out, n);
+    // wino3 addresses activations through 32-bit buffer offsets: n * 128 planes * 960 B must stay below 2^31
+    if (e->trunk_kernel == 3 && L.upk2 && (long long)n * 128 * 960 < (1ll << 31)) return launch_trunk_wino3(e, L, in, resid, out, n);
+    if (e->trunk_kernel >= 2 && L.upk2) return launch_trunk_wino2(e, L, in, resid, out, n);
     if (e->trunk_kernel == 1 && L.upk) return launch_trunk_wino(e, L, in, resid, out, n);
     if (e->trunk_waves == 8) return launch_trunk_ring_t<8>(e, L, in, resid, out, n);
     return launch_trunk_ring_t<4>(e, L, in, resid, out, n);
@@ -596,7 +620,7 @@ apz_engine* apz_create(const apz_config* cfg) {
         return bail("hipStreamCreate", err);
     e->ring = cfg->net_kind == APZ_NET_RESNET && cfg->height == 15 && cfg->width == 15 && cfg->n_filter == 128;
     if (const char* tk = getenv("APZ_TRUNK_KERNEL"))
-        e->trunk_kernel = std::string(tk) == "ring" ? 0 : std::string(tk) == "wino" ? 1 : 2;
+        e->trunk_kernel = std::string(tk) == "ring" ? 0 : std::string(tk) == "wino" ? 1 : std::string(tk) == "wino2" ? 2 : 3;
     if (const char* tw = getenv("APZ_TRUNK_WAVES")) e->trunk_waves = (atoi(tw) == 8) ? 8 : 4;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;

@@ -300,8 +300,9 @@ def test_empty_and_ragged_batches(resnet3):
 
 
 def _net_with_trunk_kernel(kind, prm, n_blocks, batch):
-    """APZ_TRUNK_KERNEL is read by apz_create: ring = direct convolution, wino / wino2 = the fused
-    F(4x4,3x3) Winograd kernels (one board / a pair of boards per workgroup)."""
+    """APZ_TRUNK_KERNEL is read by apz_create: ring = direct convolution, wino / wino2 / wino3 = the fused
+    F(4x4,3x3) Winograd kernels (one board / a pair of boards in two position passes / a pair of boards x
+    64 output channels in one pass, the default)."""
     from alphapig_amd.policy_value_net import PolicyValueNet
     old = os.environ.get("APZ_TRUNK_KERNEL")
     os.environ["APZ_TRUNK_KERNEL"] = kind
@@ -316,12 +317,12 @@ def _net_with_trunk_kernel(kind, prm, n_blocks, batch):
 
 @pytest.mark.parametrize("n", [1, 2, 7, 33])
 def test_trunk_kernels_against_oracle(n):
-    """Every trunk kernel variant (direct, Winograd, Winograd pair) against the float64 oracle: layer
+    """Every trunk kernel variant (direct, Winograd, Winograd pair, single-pass pair) against the float64 oracle: layer
     outputs of a plain and of a residual trunk convolution, logits within the path's 1e-4."""
     prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=11, style="bench")
     _, planes = random_positions(n, 15, seed=300 + n)
     o_logits, _, o_vlog, _, (o_stem, o_trunk) = net_ref.forward(prm, planes, "resnet", 2, np.float64, True)
-    for kind in ("ring", "wino", "wino2"):
+    for kind in ("ring", "wino", "wino2", "wino3"):
         net = _net_with_trunk_kernel(kind, prm, 2, 64)
         try:
             logits, _, vlog, _ = net.forward_with_logits(planes)
@@ -341,22 +342,23 @@ def test_trunk_kernels_agree_on_a_large_ragged_batch():
     prm = weights.init_params("resnet", 15, 15, 9, 1, 128, seed=12, style="bench")
     _, planes = random_positions(n, 15, seed=77)
     outs = {}
-    for kind in ("ring", "wino", "wino2"):
+    for kind in ("ring", "wino", "wino2", "wino3"):
         net = _net_with_trunk_kernel(kind, prm, 1, n)
         try:
             p, v = net.forward_planes(planes)
             outs[kind] = (p, v, net.layer_output(1, n), net.layer_output(2, n))
         finally:
             net.close()
-    for kind in ("wino", "wino2"):
+    for kind in ("wino", "wino2", "wino3"):
         for a, b in zip(outs[kind], outs["ring"]):
             np.testing.assert_allclose(a, b, rtol=0, atol=5e-5, err_msg=kind)
     # the same board gives the same bits wherever it sits in the batch (position-independent kernels)
-    net = _net_with_trunk_kernel("wino2", prm, 1, n)
-    try:
-        perm = np.random.RandomState(0).permutation(n)
-        p2, v2 = net.forward_planes(planes[perm])
-        np.testing.assert_array_equal(p2, outs["wino2"][0][perm])
-        np.testing.assert_array_equal(v2, outs["wino2"][1][perm])
-    finally:
-        net.close()
+    for kind in ("wino2", "wino3"):
+        net = _net_with_trunk_kernel(kind, prm, 1, n)
+        try:
+            perm = np.random.RandomState(0).permutation(n)
+            p2, v2 = net.forward_planes(planes[perm])
+            np.testing.assert_array_equal(p2, outs[kind][0][perm])
+            np.testing.assert_array_equal(v2, outs[kind][1][perm])
+        finally:
+            net.close()
