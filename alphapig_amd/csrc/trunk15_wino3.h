@@ -90,7 +90,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                                                             int n) {
     using T = Wino3;
 #ifdef APZ_WINO3_STAMPS
-    // phases: 0 prologue, 1 barrier wait, 2 chunk body (staging + transform + MFMA), 3 epilogue, 7 total
+    // phases: 0 prologue, 1 barrier wait, 2 chunk body (staging + transform + MFMA); epilogue: 3 compute, 4 barrier waits,
+    // 5 residual wait + staging, 6 stores; 7 total
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t = __builtin_readcyclecounter();
     const unsigned long long st_t0 = st_t;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t r_res =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESID ? resid : in), 0, act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, T::C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_u =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(upk), 0, (unsigned)(Wino2::UPK_FLOATS * 4), 0x00020000);
     auto bload = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         rg[0] = bload(r_in, st_vo, so);
         rg[1] = bload(r_in, st_vo2, so);
     };
-    auto raw_store = [&](int g) {               // registers -> raw LDS buffer g&1
-        float* dst = rawb + (g & 1) * T::RAW_FLOATS + T::RFRONT + (tid >> 5) * T::RPS;
+    auto raw_store = [&](int par) {             // registers -> raw LDS buffer `par` (= iteration & 1)
+        float* dst = rawb + par * T::RAW_FLOATS + T::RFRONT + (tid >> 5) * T::RPS;
         *reinterpret_cast<f32x4*>(dst + (st_k >> 2) * T::RROW + (st_k & 3) * 4) = rg[0];
         *reinterpret_cast<f32x4*>(dst + (st_k2 >> 2) * T::RROW + (st_k2 & 3) * 4) = rg[1];
     };
@@ -180,17 +182,17 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     // temporaries are named here so that a slice can pick up where the previous one stopped.
     //   slices 0..2: LDS reads of the five patch rows, as column pairs that need no register moves:
     //                xr[i][0] = (col -1, col 4) (one ds_read2_b32), xr[i][1] = (col 0, col 1), xr[i][2] = (col 2, col 3);
-    //   slices 2..7: B^T over the rows, row by row as they arrive (elementwise in the columns):
+    //   slices 3..7: B^T over the rows (elementwise in the columns), 18 packed operations:
     //                ph 0: y0 = 4x0 - 5x2 + x4, y1 = a + b, y2 = a - b with a = x4 - 4x2, b = x3 - 4x1   (x = patch rows 0..4)
     //                ph 1: y3 = c + 2d, y4 = c - 2d with c = z3 - z1, d = z2 - z0, y5 = 4z0 - 5z2 + z4  (z = patch rows 1..5)
     //   slices 8..16: B^T over the columns of each of the three rows (wino2_bt6's formulas), three slices per row,
     //                the row's three ds_write_b64 in its last slice.
     f32x2 xr[5][3], u0[3], u1[3], u2[3], tt[3][3];
     float o14[4];
-    auto tslice = [&](int g, auto KK) {         // raw[g&1] -> V[g&1], rows 3ph .. 3ph+2; slice KK of 18
+    auto tslice = [&](int par, auto KK) {       // raw[par] -> V[par], rows 3ph .. 3ph+2; slice KK of 18
         constexpr int K = decltype(KK)::value;
-        const float* rp = rawb + (g & 1) * T::RAW_FLOATS + tr_off;
-        float* vp = vb + (g & 1) * T::V_FLOATS + tv_off;
+        const float* rp = rawb + par * T::RAW_FLOATS + tr_off;
+        float* vp = vb + par * T::V_FLOATS + tv_off;
         auto load_row = [&](int i) {
             xr[i][0] = f32x2{rp[i * T::RROW - 1], rp[i * T::RROW + 4]};
             const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
@@ -205,42 +207,18 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
             load_row(3);
         } else if constexpr (K == 2) {
             load_row(4);
+        } else if constexpr (K == 3) {          // ph 0: b = x3 - 4 x1;  ph 1: c = z3 - z1
 #pragma unroll
-            for (int cp = 0; cp < 3; cp++) {
-                u0[cp] = 4.f * xr[0][cp];
-                if (ph == 1) u2[cp] = -xr[0][cp];
-            }
-        } else if constexpr (K == 3) {
+            for (int cp = 0; cp < 3; cp++) u2[cp] = ph == 0 ? fma2(-4.f, xr[1][cp], xr[3][cp]) : xr[3][cp] - xr[1][cp];
+        } else if constexpr (K == 4) {          // ph 0: a = x4 - 4 x2;  ph 1: d = z2 - z0
 #pragma unroll
-            for (int cp = 0; cp < 3; cp++) {
-                if (ph == 0)
-                    u2[cp] = -4.f * xr[1][cp];
-                else
-                    u1[cp] = -xr[1][cp];
-            }
-        } else if constexpr (K == 4) {
+            for (int cp = 0; cp < 3; cp++) u1[cp] = ph == 0 ? fma2(-4.f, xr[2][cp], xr[4][cp]) : xr[2][cp] - xr[0][cp];
+        } else if constexpr (K == 5) {          // both: x4 - 5 x2 (z4 - 5 z2)
 #pragma unroll
-            for (int cp = 0; cp < 3; cp++) {
-                u0[cp] = fma2(-5.f, xr[2][cp], u0[cp]);
-                if (ph == 0)
-                    u1[cp] = -4.f * xr[2][cp];
-                else
-                    u2[cp] = u2[cp] + xr[2][cp];
-            }
-        } else if constexpr (K == 5) {
+            for (int cp = 0; cp < 3; cp++) u0[cp] = fma2(-5.f, xr[2][cp], xr[4][cp]);
+        } else if constexpr (K == 6) {          // y0 = 4 x0 + (x4 - 5 x2)   (y5 = 4 z0 + (z4 - 5 z2))
 #pragma unroll
-            for (int cp = 0; cp < 3; cp++) {
-                if (ph == 0)
-                    u2[cp] = u2[cp] + xr[3][cp];
-                else
-                    u1[cp] = u1[cp] + xr[3][cp];
-            }
-        } else if constexpr (K == 6) {
-#pragma unroll
-            for (int cp = 0; cp < 3; cp++) {
-                u0[cp] = u0[cp] + xr[4][cp];
-                if (ph == 0) u1[cp] = u1[cp] + xr[4][cp];
-            }
+            for (int cp = 0; cp < 3; cp++) u0[cp] = fma2(4.f, xr[0][cp], u0[cp]);
         } else if constexpr (K == 7) {
 #pragma unroll
             for (int cp = 0; cp < 3; cp++) {
@@ -249,8 +227,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                     tt[1][cp] = u1[cp] + u2[cp];
                     tt[2][cp] = u1[cp] - u2[cp];
                 } else {
-                    tt[0][cp] = fma2(2.f, u2[cp], u1[cp]);
-                    tt[1][cp] = fma2(-2.f, u2[cp], u1[cp]);
+                    tt[0][cp] = fma2(2.f, u1[cp], u2[cp]);
+                    tt[1][cp] = fma2(-2.f, u1[cp], u2[cp]);
                     tt[2][cp] = u0[cp];
                 }
             }
@@ -269,15 +247,20 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
             } else {
                 const float o0 = __builtin_fmaf(4.f, v0, __builtin_fmaf(-5.f, v2, v4));
                 const float o5 = __builtin_fmaf(4.f, v1, __builtin_fmaf(-5.f, v3, v5));
-                *reinterpret_cast<f32x2*>(vp + (ii * 3 + 0) * T::VPP) = f32x2{o0, o14[0]};
-                *reinterpret_cast<f32x2*>(vp + (ii * 3 + 1) * T::VPP) = f32x2{o14[1], o14[2]};
-                *reinterpret_cast<f32x2*>(vp + (ii * 3 + 2) * T::VPP) = f32x2{o14[3], o5};
+                // two scalar stores per position pair: ds_write2_b32 takes any two registers (a b64 store wants an
+                // aligned pair and costs a v_mov per value)
+                vp[(ii * 3 + 0) * T::VPP] = o0;
+                vp[(ii * 3 + 0) * T::VPP + 1] = o14[0];
+                vp[(ii * 3 + 1) * T::VPP] = o14[1];
+                vp[(ii * 3 + 1) * T::VPP + 1] = o14[2];
+                vp[(ii * 3 + 2) * T::VPP] = o14[3];
+                vp[(ii * 3 + 2) * T::VPP + 1] = o5;
             }
         }
     };
 #define APZ3_ALL18(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17)
-    auto transform = [&](int g) {               // the whole transform at once (prologue)
-#define APZ3_TS(k) tslice(g, std::integral_constant<int, k>{});
+    auto transform = [&](int par) {             // the whole transform at once (prologue)
+#define APZ3_TS(k) tslice(par, std::integral_constant<int, k>{});
         APZ3_ALL18(APZ3_TS)
 #undef APZ3_TS
     };
@@ -316,13 +299,11 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     for (int v = 0; v < 5; v++) ur[v] = uload(0, v);
     APZ3_STAMP(0)
 
-    const int ety = j >> 2, etx = j & 3;
-    float* sw = stg + wave * (4 * T::SPLANE);
-    const int s_own = q * T::SPLANE + (4 * ety) * T::SROW + 4 * etx;        // this lane's 4x4 patch (row a: + a*SROW)
-    const int s_lin = (lane >> 2) * T::SROW + (lane & 3) * 4;               // plane piece `lane` (row lane>>2, quarter lane&3)
-    float* xw_own = xb + wave * T::XW + lane * 4;
-    const float* xw_oth = xb + (wave ^ 4) * T::XW + lane * 4;
-
+#if defined(APZ3_PRIO) && APZ3_PRIO == 1
+    if (ph == 1) __builtin_amdgcn_s_setprio(1);     // the later-dispatched half loses issue arbitration by age
+#elif defined(APZ3_PRIO) && APZ3_PRIO == 2
+    if (ph == 0) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int t = 0; t < nitems; t++) {
         const int h = t & 1;
         const int bd0 = 2 * ((int)blockIdx.x + (t >> 1) * (int)gridDim.x);
@@ -333,19 +314,27 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #pragma unroll
             for (int p = 0; p < 18; p++) acc[b][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int c = 0; c < T::NCHUNK; c++) {
-            const int g = t * T::NCHUNK + c;
-            __syncthreads();                    // V[g&1] complete, V[(g+1)&1] and raw[g&1] free, raw[(g+1)&1] visible
+        // One chunk = 18 slots of 4 MFMAs (k-step s = slot / 9, position pair m = slot % 9, both boards).  A slot reads
+        // the B operands of the NEXT slot, issues its MFMAs, runs one slice of the transform of chunk g+1 and, when a
+        // weight piece has seen its last MFMA, refills it for the next k-step.  sched_barrier(0) pins the slots: left
+        // alone, hipcc clusters the transform in front of the MFMAs and sinks the weight loads to their use.
+        // The chunk loop is unrolled by two so that the LDS buffer parity (g & 1 == c & 1) is a compile-time
+        // constant: every LDS address is then a loop-invariant register + immediate, no per-chunk address VALU.
+#if defined(APZ3_PRIO) && APZ3_PRIO == 3
+#define APZ3_SLOT_PRIO(k) if ((k) % 3 == 0) __builtin_amdgcn_s_setprio((((k) / 3) + ph) & 1);
+#else
+#define APZ3_SLOT_PRIO(k)
+#endif
+        auto chunk = [&](int g, auto PAR) {
+            constexpr int par = decltype(PAR)::value;
+            __syncthreads();                    // V[par] complete, V[1-par] and raw[par] free, raw[1-par] visible
             APZ3_STAMP(1)
-            // 18 slots of 4 MFMAs (k-step s = slot / 9, position pair m = slot % 9, both boards).  A slot reads the B
-            // operands of the NEXT slot, issues its MFMAs, runs one slice of the transform of chunk g+1 and, when a
-            // weight piece has seen its last MFMA, refills it for the next k-step.  sched_barrier(0) pins the slots:
-            // left alone, hipcc clusters the transform in front of the MFMAs and sinks the weight loads to their use.
-            const float* vp = vb + (g & 1) * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+            const float* vp = vb + par * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
             f32x2 bc0 = *reinterpret_cast<const f32x2*>(vp), bc1 = *reinterpret_cast<const f32x2*>(vp + 256);
 #define APZ3_SLOT(k)                                                                                               \
             {                                                                                                      \
                 constexpr int s = (k) / 9, m = (k) % 9, sn = ((k) + 1) / 9, mn = ((k) + 1) % 9;                        \
+                APZ3_SLOT_PRIO(k)                                                                                  \
                 f32x2 bn0 = bc0, bn1 = bc1;                                                                        \
                 if ((k) + 1 < 18) {                                                                                \
                     bn0 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + sn * 128);                            \
@@ -356,9 +345,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 acc[1][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc1[0], acc[1][2 * m], 0, 0, 0);          \
                 acc[0][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc0[1], acc[0][2 * m + 1], 0, 0, 0);  \
                 acc[1][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc1[1], acc[1][2 * m + 1], 0, 0, 0);  \
-                if ((k) == 0) raw_store(g + 2);                                                                    \
+                if ((k) == 0) raw_store(par);             /* raw(g+2) */                                            \
                 if ((k) == 1) raw_fetch(g + 3);                                                                    \
-                tslice(g + 1, std::integral_constant<int, (k)>{});                                                 \
+                tslice(1 - par, std::integral_constant<int, (k)>{});   /* chunk g+1 */                             \
                 if ((m & 1) || m == 8) ur[m >> 1] = uload(2 * g + s + 1, m >> 1);                                  \
                 bc0 = bn0;                                                                                         \
                 bc1 = bn1;                                                                                         \
@@ -367,6 +356,10 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
             APZ3_ALL18(APZ3_SLOT)
 #undef APZ3_SLOT
             APZ3_STAMP(2)
+        };
+        for (int c = 0; c < T::NCHUNK; c += 2) {
+            chunk(t * T::NCHUNK + c, std::integral_constant<int, 0>{});
+            chunk(t * T::NCHUNK + c + 1, std::integral_constant<int, 1>{});
         }
 
         // ---- epilogue of the item.  Lane (q, j): tile j = 4*ety + etx, channels cot*16 + 4q + r.
@@ -378,8 +371,19 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         // never stored.
         const int cot = 4 * h + ct;
         const int bd_own = (ph == 0 || !two) ? bd0 : bd0 + 1;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cot * 16 + q * 4);
-        const unsigned ep_vo = lane < 60 ? lane * 16 : 0x80000000u;             // piece `lane` of a plane; lanes 60..63 out of range
+        // The epilogue's per-lane addresses are derived from an opaque copy of the lane id: computed from `lane` they
+        // are loop invariants, hipcc keeps them in registers across the chunk loop (which has none to spare) and
+        // spills them -- and every scratch reload is followed by vmcnt(0), a full drain of the loads and stores in flight.
+        int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id, rematerialised (2 VALU)
+        asm volatile("" : "+v"(le));
+        const int eq = le >> 4, ety = (le >> 2) & 3, etx = le & 3;
+        float* sw = stg + wave * (4 * T::SPLANE);
+        const int s_own = eq * T::SPLANE + (4 * ety) * T::SROW + 4 * etx;       // this lane's 4x4 patch (row a: + a*SROW)
+        const int s_lin = (le >> 2) * T::SROW + (le & 3) * 4;                   // plane piece `lane` (row lane>>2, quarter lane&3)
+        float* xw_own = xb + wave * T::XW + le * 4;
+        const float* xw_oth = xb + (wave ^ 4) * T::XW + le * 4;
+        const f32x4 bv = bload(r_bias, (unsigned)(eq * 16), (unsigned)(cot * 64));
+        const unsigned ep_vo = le < 60 ? le * 16 : 0x80000000u;                 // piece `lane` of a plane; lanes 60..63 out of range
         const unsigned st_out_vo = ((ph == 0) || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch: stores dropped
         auto plane_so = [&](int r, int qp) {                                    // plane q' of step r
             return (unsigned)__builtin_amdgcn_readfirstlane(bd_own * T::C + cot * 16 + qp * 4 + r) * plane_b;
@@ -406,25 +410,40 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         };
         {
             constexpr int own = ph;             // static register indices
-            f32x4 win[4];
+            f32x4 winb[2][4];                   // residual planes in flight: step r in winb[r & 1]
             auto resid_load = [&](int r) {
 #pragma unroll
-                for (int qp = 0; qp < 4; qp++) win[qp] = bload(r_res, ep_vo, plane_so(r, qp));
+                for (int qp = 0; qp < 4; qp++) winb[r & 1][qp] = bload(r_res, ep_vo, plane_so(r, qp));
             };
-            if (RESID) resid_load(0);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 f32x4 ps[3];
                 partial(acc[1 - own], r, ps);
+                APZ3_STAMP(3)
                 __syncthreads();                // r = 0: every wave's MFMAs over V[1] are done; r > 0: X of step r-1 consumed
+                APZ3_STAMP(4)
 #pragma unroll
                 for (int v = 0; v < 3; v++) *reinterpret_cast<f32x4*>(xw_own + v * 256) = ps[v];
+                // residual planes of step 0: only now -- at the top of the epilogue all 144 accumulators are live and
+                // 16 more registers in flight spill; the planes of step 1 follow after this step's second partial, those
+                // of steps 2, 3 here, one step ahead.  Always BEFORE the step's stores: vmcnt counts in issue order, so
+                // the wait for these loads leaves the stores in flight instead of draining them.
+                if (RESID && r >= 1 && r + 1 < 4) resid_load(r + 1);   // ~one step ahead of its use
+                if (RESID && r == 0) resid_load(0);
+                f32x4 (&win)[4] = winb[r & 1];
 #ifdef APZ3_DEBUG_X
                 if (blockIdx.x == 0 && t == 0)
                     *reinterpret_cast<f32x4*>(&apz_wino3_dbg[(((wave * 4 + r) * 2 + 0) * 64 + lane) * 4]) = ps[2];
 #endif
                 f32x4 po[3];
                 partial(acc[own], r, po);
+                if (RESID && r == 0) resid_load(1);     // (both boards' r = 0 accumulator components are dead now)
+                APZ3_STAMP(3)
+                __syncthreads();                // X of step r complete
+                APZ3_STAMP(4)
+                f32x4 px[3];
+#pragma unroll
+                for (int v = 0; v < 3; v++) px[v] = *reinterpret_cast<const f32x4*>(xw_oth + v * 256);
                 f32x4 w4[4];
                 if (RESID) {                    // plane pieces -> staging -> this lane's 4x4 patch
 #pragma unroll
@@ -433,12 +452,11 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #pragma unroll
                     for (int a = 0; a < 4; a++) w4[a] = *reinterpret_cast<const f32x4*>(sw + s_own + a * T::SROW);
                     APZ3_FENCE();
-                    if (r + 1 < 4) resid_load(r + 1);
+#ifdef APZ_WINO3_STAMPS
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    APZ3_STAMP(5)
                 }
-                __syncthreads();                // X of step r complete
-                f32x4 px[3];
-#pragma unroll
-                for (int v = 0; v < 3; v++) px[v] = *reinterpret_cast<const f32x4*>(xw_oth + v * 256);
 #ifdef APZ3_DEBUG_X
                 if (blockIdx.x == 0 && t == 0)
                     *reinterpret_cast<f32x4*>(&apz_wino3_dbg[(((wave * 4 + r) * 2 + 1) * 64 + lane) * 4]) = px[2];
@@ -465,12 +483,15 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #pragma unroll
                 for (int qp = 0; qp < 4; qp++) pv[qp] = *reinterpret_cast<const f32x4*>(sw + qp * T::SPLANE + s_lin);
                 APZ3_FENCE();
+                // next step's residual planes BEFORE this step's stores: vmcnt counts in issue order, so the wait for
+                // these loads then leaves the four stores in flight instead of draining them
+                APZ3_STAMP(3)
 #pragma unroll
                 for (int qp = 0; qp < 4; qp++)
                     bstore(r_out, st_out_vo, plane_so(r, qp), pv[qp]);
             }
         }
-        APZ3_STAMP(3)
+        APZ3_STAMP(6)
     }
     };
     if ((wave >> 2) == 0)

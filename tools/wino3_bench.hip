@@ -222,7 +222,7 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         unsigned long long hst[4 * 8 * 8];
         CK(hipMemcpyFromSymbol(hst, HIP_SYMBOL(apz::apz_wino3_stamps), sizeof(hst)));
-        const char* names[8] = {"prologue", "barrier", "body", "epilogue", "-", "-", "-", "total"};
+        const char* names[8] = {"prologue", "barrier", "body", "epi-compute", "epi-barrier", "epi-resid", "epi-store", "total"};
         for (int wg = 0; wg < 2; wg++)
             for (int w = 0; w < 8; w++) {
                 printf("wg %d wave %d:", wg, w);
