@@ -15,7 +15,7 @@
 // wino2); it is spread over all 512 threads (half a 6x6 tile each) and sits inside each wave's own
 // MFMA stream, where a VALU instruction costs ~4 cycles instead of one MFMA slot (tools/mfma_valu_probe).
 //
-// Work item t of a workgroup = (board pair t>>1, channel half h = t&1).  Wave w: ct = w&3 (16 output
+// Work item of a workgroup = (board pair, channel half h) (mapping: see the kernel).  Wave w: ct = w&3 (16 output
 // channels cot*16.., cot = 4h + ct), ph = w>>2 (transformed rows 3ph..3ph+2 = 18 positions), both
 // boards: 2 x 18 x 4 = 144 accumulator registers.  Per item the 128 input channels stream through in
 // 16 chunks of 8, one barrier per chunk:
@@ -120,11 +120,24 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     for (int i = tid; i < T::STAGE_FLOATS; i += 512) stg[i] = 777.f;
 #endif
 
-    const int npairs = (n + 1) >> 1;
-    const int np = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // board pairs of this workgroup
-    const int nitems = 2 * np;
+    // ---- work items of this workgroup.  Item = (board pair, channel half h).
+    // Grids that are a multiple of 16 run in "duo" mode: two workgroups that the dispatcher (observed: round-robin
+    // over the 8 XCDs) places on the same XCD take the two channel halves of the SAME pairs at the same time, so
+    // the second read of a pair's input planes is an L2 hit instead of a second trip over the fabric.  Placement
+    // changes only speed: any other grid (and any other placement) computes the same thing.
+    // duo:   block b -> XCD group c = b % 8, i = b / 8; duo d = (i / 2) * 8 + c takes pairs d, d + G/2, ...; h = i & 1.
+    // plain: block b takes pairs b, b + G, ... and both halves of each.
+    const int npairs = (n + 1) >> 1, G_ = (int)gridDim.x, b_ = (int)blockIdx.x;
+    const bool duo = (G_ & 15) == 0;
+    const int pair0 = duo ? ((b_ >> 4) * 8 + (b_ & 7)) : b_;
+    const int pstride = duo ? (G_ >> 1) : G_;
+    const int h_fix = (b_ >> 3) & 1;            // duo mode: this workgroup's channel half
+    const int np = pair0 < npairs ? (npairs - pair0 + pstride - 1) / pstride : 0;   // board pairs of this workgroup
+    const int nitems = duo ? np : 2 * np;
     const int total_iters = nitems * T::NCHUNK;
-    if (np == 0) return;                        // (launchers never oversubscribe; uniform, before any barrier)
+    if (np == 0) return;                        // (uniform, before any barrier)
+    auto item_pair = [&](int t) { return pair0 + (duo ? t : (t >> 1)) * pstride; };
+    auto item_half = [&](int t) { return duo ? h_fix : (t & 1); };
 
     // All global memory traffic goes through raw buffer instructions: descriptor (SGPRs) + per-lane 32-bit offset
     // + wave-uniform SGPR offset.  No 64-bit per-lane addresses (registers, VALU), and lanes that must not take
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     f32x4 rg[2];
     auto raw_fetch = [&](int g) {               // global -> registers (iteration g of this workgroup's stream, clamped)
         g = g < total_iters ? g : total_iters - 1;
-        const int bdp = 2 * ((int)blockIdx.x + (g / (2 * T::NCHUNK)) * (int)gridDim.x) + (wave >> 2), c = g & (T::NCHUNK - 1);
+        const int bdp = 2 * item_pair(g / T::NCHUNK) + (wave >> 2), c = g & (T::NCHUNK - 1);
         const int bd = bdp < n ? bdp : n - 1;
         const unsigned so = (unsigned)(bd * T::C + c * T::CK) * plane_b;
         rg[0] = bload(r_in, st_vo, so);
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     // piece v refilled right after its last MFMA with the same piece of the next k-step (28 MFMAs ahead).
     const unsigned ulane = lane * (T::UROW * 4);
     auto uload = [&](int ks, int v) {           // ks = global k-step of this workgroup's stream (32 per item), v = piece 0..4
-        const int hh = (ks >> 5) & 1, kk = ks & 31;
+        const int hh = item_half(ks >> 5), kk = ks & 31;
         const unsigned so = (unsigned)(((hh * 4 + ct) * 2 + ph) * 32 + kk) * (T::USTEP * 4);
         if (v == 4) {                           // values 16, 17 (+ 2 pad floats that are never loaded: dead registers under an
             const auto w = __builtin_amdgcn_raw_buffer_load_b64(r_u, ulane + 64, so, 0);   // in-flight load get reused -> WAW waits)
@@ -305,8 +318,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     if (ph == 0) __builtin_amdgcn_s_setprio(1);
 #endif
     for (int t = 0; t < nitems; t++) {
-        const int h = t & 1;
-        const int bd0 = 2 * ((int)blockIdx.x + (t >> 1) * (int)gridDim.x);
+        const int h = item_half(t);
+        const int bd0 = 2 * item_pair(t);
         const bool two = bd0 + 1 < n;           // the last pair of an odd batch has one board (computed twice, stored once)
         f32x4 acc[2][18];
 #pragma unroll

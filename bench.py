@@ -14,12 +14,16 @@ select -> (leaf) -> expand/backup for one playout and the 1024 leaves are evalua
 Reported `value` = self-play games/s = (playouts completed in the timed region / n_playout)
 plies / (mean plies per game) / seconds, aggregated over ranks (weak scaling: 1024 games per
 GPU).  Mean plies per game is a property of the workload, measured by playing complete games
-with this exact configuration (`--full-games`, result cached in profiles/calibration_r01.json);
-`leaf_evals_per_s` (directly counted) is printed alongside.
+with this exact configuration (`--full-games` / `--count-games`, cached in profiles/calibration_r*.json);
+`leaf_evals_per_s` (directly counted) is printed alongside.  `--count-games SECONDS` counts
+finished games directly in a steady-state window (continuous refill; minutes).
 
-Extra objects on the JSON line: `roofline` (dominant kernel = trunk 3x3 conv, fp32 matrix pipe),
-`roofline_stem` (north_star's HBM target shape 8192x4x15x15 and the real C_in=9 stem),
-`cpu_baseline` (sequential CPU oracle port, 1 core, bounded sample).
+`--gpus N` without a torchrun environment starts the N ranks itself (fresh child processes, one per
+GPU, RCCL over 127.0.0.1); under `python -m torch.distributed.run` the ranks are the launcher's.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = trunk 3x3 conv, fp32 matrix pipe;
+`frac` = EXECUTED MFMA flops / time / peak), `roofline_stem` (north_star's HBM target shape
+8192x4x15x15 and the real C_in=9 stem), `cpu_baseline` (sequential CPU oracle port, bounded sample).
 """
 import argparse
 import json
@@ -128,6 +132,51 @@ def stem_roofline(device):
     return out
 
 
+def spawn_ranks(n, argv):
+    """`--gpus N` outside a launcher: start N fresh rank processes (this process has not touched the GPU and
+    never does), pass rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), APZ_BENCH_SELF_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=REPO,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
+def host_cpu_share():
+    """CPUs this process may use: affinity mask, capped by the cgroup CPU quota (a 1-GPU box shows 256 CPUs and
+    grants 16 cores' worth of time; all ranks of a node share it)."""
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            ncpu = min(ncpu, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return ncpu
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +186,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2)
     ap.add_argument("--full-games", type=int, default=0, help="play this many COMPLETE games per GPU "
                     "instead of timing --steps (measures games/s and mean plies directly; minutes)")
+    ap.add_argument("--count-games", type=float, default=0.0, metavar="SECONDS",
+                    help="count finished games over a steady-state window of this many seconds (continuous refill; the "
+                         "window opens once every slot has finished a game or after --count-warmup-max seconds)")
+    ap.add_argument("--count-warmup-max", type=float, default=420.0)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # child of cpu_baseline()
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
@@ -150,27 +203,16 @@ def main():
         print(json.dumps({"n": n_, "dt": dt_}))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])          # before anything touches the GPU
     rank, world, local = dist.init(backend="gloo" if args.plumbing_test else None)
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     from alphapig_amd.policy_value_net import PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
 
-    # host threads for the tree pool: this process's CPU share (a 1-GPU box grants 16 cores; the
-    # host may show many more), split evenly between the ranks of a node
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    # a GPU box also grants a CPU QUOTA (cgroup v2 cpu.max = "quota period"): 256 visible CPUs but 16 cores' worth
-    # of time on a 1-GPU share; all ranks of a node share it
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            ncpu = min(ncpu, max(1, int(quota) // int(period)))
-    except (OSError, ValueError):
-        pass
+    # host threads for the tree pool: this node's CPU share split evenly between its ranks
+    ncpu = host_cpu_share()
     threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(world, 1)))
     G = args.games
     if args.plumbing_test:
@@ -238,6 +280,51 @@ def main():
         for ln in lanes:
             ln.close()
         return
+    if args.count_games > 0:
+        # Steady state, counted: slots are refilled the moment a game ends; once every slot has finished at least one
+        # game (so the mix of game ages is the stationary one) finished games are counted over a fixed window.
+        t_start = time.perf_counter()
+        last = t_start
+        all_done_at = None
+        while True:
+            eng.run_steps(64)
+            now = time.perf_counter()
+            frac = float(np.mean(eng.slot_games > 0))
+            if frac == 1.0 or now - t_start > args.count_warmup_max:
+                all_done_at = now - t_start
+                break
+            if now - last > 20.0:
+                print("[count-games] warm-up %.0fs: %.1f%% of the slots have finished a game, %d games" %
+                      (now - t_start, 100 * frac, eng.stats["games"]), file=sys.stderr, flush=True)
+                last = now
+        dist.barrier()
+        g0, p0_, l0_ = eng.stats["games"], eng.stats["plies"], eng.stats["leaf_evals"]
+        t0 = time.perf_counter()
+        last = t0
+        while time.perf_counter() - t0 < args.count_games:
+            eng.run_steps(64)
+            if time.perf_counter() - last > 20.0:
+                print("[count-games] window %.0fs: %d games" % (time.perf_counter() - t0, eng.stats["games"] - g0),
+                      file=sys.stderr, flush=True)
+                last = time.perf_counter()
+        for ln in lanes:
+            ln.sync()
+        dt = dist.all_reduce_max(time.perf_counter() - t0)
+        games = dist.all_reduce_sum(eng.stats["games"] - g0)
+        plies = dist.all_reduce_sum(eng.stats["plies"] - p0_)
+        leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0_)
+        if rank == 0:
+            mp = plies / max(games, 1)
+            print(json.dumps({"mode": "count-games", "games_in_window": int(games), "window_s": dt,
+                              "games_per_s_counted": games / dt, "mean_plies_per_game": mp,
+                              "leaf_evals_per_s": leafs / dt,
+                              "games_per_s_derived": leafs / dt / (N_PLAYOUT * mp) if games else None,
+                              "warmup_s": all_done_at, "slots_with_a_finished_game": float(np.mean(eng.slot_games > 0)),
+                              "n_gpus": world, "games_per_gpu_concurrent": G, "host_threads_per_rank": threads}))
+        eng.close()
+        for ln in lanes:
+            ln.close()
+        return
     if mean_plies is None:
         raise SystemExit("profiles/calibration_r01.json missing: run `python bench.py --full-games 1024` once")
 
@@ -272,6 +359,7 @@ def main():
     dist.barrier()
     dt_local = time.perf_counter() - t0
     dt = dist.all_reduce_max(dt_local)
+    ranks_seen = int(round(dist.all_reduce_sum(1)))
     playouts = dist.all_reduce_sum(playouts_done() - p0)
     leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0)
     trunk_ms = trunk_cnt = 0
@@ -287,27 +375,33 @@ def main():
 
     games_per_s = playouts / N_PLAYOUT / mean_plies / dt
     batch = G // args.pipeline
-    # which trunk kernel ran (apz_engine.hip reads the same variable; default = the Winograd pair kernel)
-    tk = os.environ.get("APZ_TRUNK_KERNEL", "wino2")
-    tk = tk if tk in ("ring", "wino") else "wino2"
-    # HBM traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
+    # which trunk kernel ran (apz_engine.hip reads the same variable; default = the single-pass Winograd pair kernel)
+    tk = os.environ.get("APZ_TRUNK_KERNEL", "wino3")
+    tk = tk if tk in ("ring", "wino", "wino2") else "wino3"
+    # HBM / fabric traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
     # (cannot be collected from inside the process), committed under profiles/
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01_trunk_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj.get("boards_per_launch") == batch and tj.get("kernel", "ring") == tk:
-            traffic = tj["traffic_bytes_per_launch"]["mean"]
+    traffic, traffic_src = None, None
+    for tname in ("r02_trunk_traffic.json", "r01_trunk_traffic.json"):
+        tpath = os.path.join(REPO, "profiles", tname)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("boards_per_launch") == batch and tj.get("kernel", "ring") == tk:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"]["mean"], "profiles/" + tname
+                break
     trunk_avg_ms = trunk_ms / max(trunk_cnt, 1)
-    achieved_tf = trunk_flops(batch) / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
     kernel_name = {"ring": "trunk15_ring_kernel<RESID,4> (direct 3x3 convolution on fp32 MFMA)",
                    "wino": "trunk15_wino_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, one board per workgroup)",
-                   "wino2": "trunk15_wino2_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, two boards per workgroup)"}[tk]
+                   "wino2": "trunk15_wino2_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, two boards per workgroup, two position passes)",
+                   "wino3": "trunk15_wino3_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, single pass: two boards x 64 output channels per work item)"}[tk]
     # MFMA flops the kernel really issues: direct = the algorithmic count on 16-wide rows; Winograd =
-    # 36 positions x 8 channel tiles x 32 k-steps of v_mfma_f32_16x16x4_f32 (2048 flop) per board
+    # 36 positions x 8 channel tiles x 32 k-steps of v_mfma_f32_16x16x4_f32 (2048 flop) per board.
+    # `achieved` / `frac` are on THIS basis (a fraction of the matrix pipe's peak, <= 1); the rate of the layer's
+    # definition (direct-convolution flops / time, which Winograd makes exceed the peak) is kept beside it.
     executed = trunk_flops(batch) * 16.0 / 15.0 if tk == "ring" else batch * 9216 * 2048.0
     executed_tf = executed / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
+    direct_tf = trunk_flops(batch) / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
+    arena_gb = eng.pool.arena_bytes() / 1e9 if hasattr(eng.pool, "arena_bytes") else None
     line = {
         "metric": "self-play games/sec (15x15, n_playout=400)", "value": games_per_s, "unit": "games/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -316,19 +410,26 @@ def main():
                                "10-block/128-filter residual net, %d concurrent games per GPU" % G,
                    "games_per_gpu": G, "leaf_batch": batch, "pipeline": args.pipeline, "host_threads": threads,
                    "mean_plies_per_game": mean_plies, "mean_plies_source": plies_src, "weights": "random init seed 0"},
+        "ranks_seen": ranks_seen, "host_threads_per_rank": threads, "host_cpu_share": ncpu,
+        "tree_arena_gb_per_rank": arena_gb,
+        "launcher": "self-spawned" if os.environ.get("APZ_BENCH_SELF_SPAWNED") else
+                    ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "single process"),
         "leaf_evals_per_s": leafs / dt,
         "playouts_per_s": playouts / dt,
         "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
         "roofline": {"kernel": kernel_name + ": trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward",
-                     "bound": "mfma", "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": (achieved_tf / FP32_MATRIX_PEAK_TF) if achieved_tf else None,
-                     "achieved_basis": "algorithmic flops of the direct 3x3 convolution (2*9*128*128*225 per board) / launch time",
-                     "executed_mfma": {"tflops": executed_tf, "frac": (executed_tf / FP32_MATRIX_PEAK_TF) if executed_tf else None,
-                                       "flops_per_launch": executed},
+                     "bound": "mfma", "achieved": executed_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": (executed_tf / FP32_MATRIX_PEAK_TF) if executed_tf else None,
+                     "achieved_basis": "MFMA flops the kernel executes (9216 v_mfma_f32_16x16x4_f32 x 2048 flop per board) / "
+                                       "average launch duration (HIP events on the engine stream inside the timed region)",
+                     "flops_per_launch": executed,
+                     "direct_conv_equivalent": {"tflops": direct_tf, "flops_per_launch": trunk_flops(batch),
+                                                "note": "SURVEY 8(d) algorithmic flops of the layer (2*9*128*128*225 per board) / the "
+                                                        "same time; exceeds the peak because Winograd executes 3.5x fewer flops"},
                      "traffic": traffic,
-                     "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_trunk_traffic.json; direct-convolution minimum 158 MB, see there)",
-                     "us_per_launch": trunk_avg_ms * 1e3, "launches": trunk_cnt,
-                     "flops_per_launch": trunk_flops(batch), "boards_per_launch": batch},
+                     "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes, %s; "
+                                     "direct-convolution minimum 158 MB, see there)" % traffic_src,
+                     "us_per_launch": trunk_avg_ms * 1e3, "launches": trunk_cnt, "boards_per_launch": batch},
     }
     eng.close()
     for ln in lanes:

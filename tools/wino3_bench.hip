@@ -91,8 +91,8 @@ int main(int argc, char** argv) {
     };
     // ---- cross-check against wino2 at ragged sizes (odd batch, fewer pairs than CUs, several pairs per workgroup)
     int bad = 0;
-    const int check_sizes[5] = {1, 7, 512, 515, 1030};
-    for (int ci = 0; ci < (getenv("APZ_NO_TIMING") ? 2 : 5); ci++) {
+    const int check_sizes[7] = {1, 7, 64, 96, 512, 515, 1030};
+    for (int ci = 0; ci < (getenv("APZ_NO_TIMING") ? 2 : 7); ci++) {
         const int n = check_sizes[ci];
         const int grid = (n + 1) / 2 < 256 ? (n + 1) / 2 : 256;
         for (int resid = 0; resid < 2; resid++) {
