@@ -85,6 +85,7 @@ def host():
         "apzh_update_with_move": (C.c_int, [vp, C.c_int, C.c_int]),
         "apzh_play_move": (C.c_int, [vp, C.c_int, C.c_int, i32p]),
         "apzh_stats": (C.c_int, [vp, C.c_int, i64p]),
+        "apzh_pool_info": (C.c_int, [vp, i64p]),
         "apzh_pure_get_move": (C.c_int, [vp, C.c_int, u32p, i32p, i32p, i64p, f64p, C.c_int, i32p]),
     }
     for name, (res, args) in sig.items():
@@ -101,7 +102,7 @@ HOST_SYMBOLS = ["apzh_last_error", "apzh_version", "apzh_create", "apzh_destroy"
                 "apzh_advance", "apzh_feed", "apzh_feed_sparse", "apzh_pending_path", "apzh_playouts_done",
                 "apzh_set_playouts_done", "apzh_set_n_playout", "apzh_node_children", "apzh_set_prior_mode",
                 "apzh_root_visits_dense", "apzh_update_with_move", "apzh_play_move", "apzh_stats",
-                "apzh_pure_get_move"]
+                "apzh_pool_info", "apzh_pure_get_move"]
 
 HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create", "apz_destroy",
                "apz_param_count", "apz_param_name", "apz_param_size", "apz_load_weights", "apz_forward",

@@ -137,6 +137,8 @@ struct apzh_pool {
     int hw;
     int nthreads;
     std::vector<Game> games;
+    int64_t arena_bytes = 0;        // address space reserved for the tree arenas of all games
+    bool arena_touched = false;     // ... and whether it was faulted in at creation
 };
 
 namespace {
@@ -438,10 +440,32 @@ apzh_pool *apzh_create(const apzh_config *cfg) {
     // 15x15 at n_playout = 400 are 8.7 GB): first-touch page faults cost more than the tree work itself
     // (feed median 0.35 ms against 0.15 ms once the pages exist) and would otherwise sit in the first
     // two searches of every slot -- most of a short benchmark window.
+    // The limit follows the memory this process may really use -- half of min(MemAvailable, cgroup memory.max),
+    // at most 96 GB -- so that the competition-strength slice (BASELINE config 5: n_playout = 1600, 1024 games,
+    // 31 GB of arenas) is touched up front as well instead of faulting its pages in inside the first searches.
     double limit_gb = 16.0;
+    {
+        double avail_gb = 0.0;
+        if (FILE *f = fopen("/proc/meminfo", "r")) {
+            char line[256];
+            while (fgets(line, sizeof line, f)) {
+                unsigned long long kb;
+                if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) avail_gb = (double)kb / 1e6;
+            }
+            fclose(f);
+        }
+        if (FILE *f = fopen("/sys/fs/cgroup/memory.max", "r")) {
+            unsigned long long b;
+            if (fscanf(f, "%llu", &b) == 1 && (avail_gb == 0.0 || (double)b / 1e9 < avail_gb)) avail_gb = (double)b / 1e9;
+            fclose(f);
+        }
+        if (avail_gb > 0.0) limit_gb = std::min(96.0, std::max(4.0, 0.5 * avail_gb));
+    }
     if (const char *s = getenv("APZ_HOST_PRETOUCH_GB")) limit_gb = atof(s);
     const double total_gb = 2.0 * (double)cfg->n_games * (double)cap * (double)Arena::bytes_per_node() / 1e9;
     const bool touch = total_gb <= limit_gb;
+    p->arena_bytes = (int64_t)(2.0 * (double)cfg->n_games * (double)cap * (double)Arena::bytes_per_node());
+    p->arena_touched = touch;
     const int ng = cfg->n_games;
 #pragma omp parallel for schedule(static) num_threads(nt) if (ng > 8)
     for (int i = 0; i < ng; i++) {
@@ -749,6 +773,17 @@ int apzh_stats(apzh_pool *p, int gi, int64_t *out4) {
     CHECK_GAME(p, gi);
     Game &g = p->games[gi];
     out4[0] = g.n_net; out4[1] = g.n_term; out4[2] = g.tree[g.cur].size(); out4[3] = g.peak_nodes;
+    return APZH_OK;
+}
+
+int apzh_pool_info(apzh_pool *p, int64_t *out4) {
+    if (!p || !out4) return fail(APZH_E_ARG, "null argument");
+    int64_t peak = 0, live = 0;
+    for (const Game &g : p->games) {
+        peak = std::max<int64_t>(peak, g.peak_nodes);
+        live += g.tree[g.cur].size();
+    }
+    out4[0] = p->arena_bytes; out4[1] = p->arena_touched ? 1 : 0; out4[2] = peak; out4[3] = live;
     return APZH_OK;
 }
 

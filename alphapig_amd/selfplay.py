@@ -82,6 +82,7 @@ class SelfPlayEngine(object):
         self.sampler = sampler
         self._sample_step = 0
         self.slots = [_Slot() for _ in range(self.G)]
+        self.slot_games = np.zeros(self.G, dtype=np.int64)      # games finished per slot (steady-state detection)
         self.next_index = 0
         self.finished = []
         self.stats = collections.Counter()
@@ -131,6 +132,7 @@ class SelfPlayEngine(object):
                                      np.stack(slot.codes), np.stack(slot.pis), z, winner))
         self.stats["games"] += 1
         self.stats["plies"] += len(movers)
+        self.slot_games[s] += 1
 
     def _temp_for(self, ply):
         sch = self.temp_schedule

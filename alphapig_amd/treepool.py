@@ -183,6 +183,14 @@ class TreePool(object):
         return dict(net_evals=int(out[0]), terminal_playouts=int(out[1]), live_nodes=int(out[2]),
                     peak_nodes=int(out[3]))
 
+    def pool_info(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.apzh_pool_info(self._h, as_ptr(out, C.c_int64)))
+        return dict(arena_bytes=int(out[0]), pretouched=bool(out[1]), peak_nodes=int(out[2]), live_nodes=int(out[3]))
+
+    def arena_bytes(self):
+        return self.pool_info()["arena_bytes"]
+
     def pure_get_move(self, g, mt_key, mt_pos, want_children=False):
         """mcts_pure get_move on slot g with the MT19937 state (key uint32[624], pos)."""
         key = np.ascontiguousarray(mt_key, dtype=np.uint32).copy()

@@ -140,24 +140,32 @@ def spawn_ranks(n, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), APZ_BENCH_SELF_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=REPO,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    sys.stdout.write(out0.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves the others waiting in a collective: watch all of them, stop everything on the first failure
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+    if failed is not None:
+        raise SystemExit("bench.py: rank %d exited with code %s; stopped the other ranks" % (failed, procs[failed].returncode))
 
 
 def host_cpu_share():
@@ -205,6 +213,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])          # before anything touches the GPU
+    if os.environ.get("APZ_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+        raise SystemExit(3)                                  # tests/test_dist_gloo.py: a rank that dies
     rank, world, local = dist.init(backend="gloo" if args.plumbing_test else None)
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))

@@ -128,6 +128,10 @@ int apzh_update_with_move(apzh_pool *p, int g, int move);
 int apzh_play_move(apzh_pool *p, int g, int move, int32_t *out3);
 /* counters: out[0]=net leaf evals out[1]=terminal leaf playouts out[2]=live nodes out[3]=peak nodes */
 int apzh_stats(apzh_pool *p, int g, int64_t *out4);
+/* pool-wide: out[0]=bytes reserved for the tree arenas, out[1]=1 if they were pre-touched at creation,
+ * out[2]=largest tree any game has held (nodes), out[3]=live nodes of all games.  (Build-side addition: the
+ * reference allocates one Python object per node, mcts_alphaZero.py:34-41, and has nothing to report.) */
+int apzh_pool_info(apzh_pool *p, int64_t *out4);
 
 /* ---- pure-MCTS move (mcts_pure.py) ------------------------------------------------------ */
 /* Runs n_playout rollout playouts from a fresh root on game g's position, drawing

@@ -76,3 +76,27 @@ def test_bench_multi_rank_plumbing(tmp_path):
     assert d["valid"] is False and d["vs_baseline"] is None and d["unit"] == "games/s"
     assert d["leaf_evals_per_s"] > 0 and d["value"] > 0
     assert d["config"]["games_per_gpu"] == 8
+    assert d["ranks_seen"] == 2 and d["host_threads_per_rank"] >= 1 and d["launcher"] == "torchrun"
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command): the parent starts
+    the two ranks itself, rank 0's single JSON line comes through, and it says so (n_gpus, ranks_seen from an
+    all-reduce, host threads per rank from the CPU share / 2)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--plumbing-test"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launcher"] == "self-spawned"
+    assert d["host_threads_per_rank"] == max(1, min(16, d["host_cpu_share"] // 2))
+    assert d["tree_arena_gb_per_rank"] > 0 and d["valid"] is False
+    # a rank that dies takes the whole command down with a non-zero exit code
+    bad = subprocess.run(cmd, env=dict(env, APZ_BENCH_TEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=120)
+    assert bad.returncode != 0 and "{" not in bad.stdout
