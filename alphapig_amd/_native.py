@@ -107,7 +107,7 @@ HOST_SYMBOLS = ["apzh_last_error", "apzh_version", "apzh_create", "apzh_destroy"
 HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create", "apz_destroy",
                "apz_param_count", "apz_param_name", "apz_param_size", "apz_load_weights", "apz_forward",
                "apz_forward_host", "apz_forward_codes_host", "apz_forward_codes_async", "apz_submit_codes", "apz_wait", "apz_host_alloc",
-               "apz_host_free", "apz_encode_planes", "apz_augment8", "apz_sample_moves_host", "apz_conv3x3_packed_size", "apz_conv3x3_pack",
+               "apz_host_free", "apz_encode_planes", "apz_augment8", "apz_sample_moves_host", "apz_sample_moves_keyed_host", "apz_conv3x3_packed_size", "apz_conv3x3_pack",
                "apz_conv3x3_fwd", "apz_conv3x3_wgrad", "apz_wino_packed_size", "apz_wino_pack", "apz_wino_conv",
                "apz_bn_fwd", "apz_bn_bwd", "apz_adam_step", "apz_wgrad_wino",
                "apz_sync", "apz_stream",
@@ -147,6 +147,8 @@ def hip():
         "apz_augment8": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
         "apz_sample_moves_host": (C.c_int, [vp, i32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
                                            f32p, i32p]),
+        "apz_sample_moves_keyed_host": (C.c_int, [vp, i32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
+                                        C.POINTER(C.c_uint64), f32p, i32p]),
         "apz_conv3x3_packed_size": (C.c_int64, [C.c_int, C.c_int]),
         "apz_conv3x3_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
         "apz_conv3x3_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -105,6 +105,7 @@ struct apz_engine {
     int32_t* smp_vis = nullptr;
     float* smp_pi = nullptr;
     int32_t* smp_mv = nullptr;
+    uint64_t* smp_keys = nullptr;
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     double* bn_sums = nullptr;                     // apz_bn_fwd / _bwd: per-channel reduction scratch
@@ -927,6 +928,12 @@ int apz_augment8(apz_engine* e, const void* planes_dev, const void* pi_dev, int 
 
 int apz_sample_moves_host(apz_engine* e, const int32_t* visits_host, int g, float temp, float alpha, float eps,
                           uint64_t seed, uint64_t step, float* pi_host, int32_t* moves_host) {
+    return apz_sample_moves_keyed_host(e, visits_host, g, temp, alpha, eps, seed, step, nullptr, pi_host, moves_host);
+}
+
+int apz_sample_moves_keyed_host(apz_engine* e, const int32_t* visits_host, int g, float temp, float alpha, float eps,
+                                uint64_t seed, uint64_t step, const uint64_t* keys_host, float* pi_host,
+                                int32_t* moves_host) {
     if (!e || !visits_host || !pi_host || !moves_host) return fail(APZ_E_ARG, "null argument");
     if (g < 1 || e->hw > 256 || !(temp > 0.f) || !(alpha > 0.f) || eps < 0.f || eps > 1.f)
         return fail(APZ_E_ARG, "bad sampler arguments");
@@ -937,15 +944,20 @@ int apz_sample_moves_host(apz_engine* e, const int32_t* visits_host, int g, floa
         if (e->smp_vis) hipFree(e->smp_vis);
         if (e->smp_pi) hipFree(e->smp_pi);
         if (e->smp_mv) hipFree(e->smp_mv);
-        e->smp_vis = nullptr; e->smp_pi = nullptr; e->smp_mv = nullptr; e->smp_cap = 0;
+        if (e->smp_keys) hipFree(e->smp_keys);
+        e->smp_vis = nullptr; e->smp_pi = nullptr; e->smp_mv = nullptr; e->smp_keys = nullptr; e->smp_cap = 0;
+        HIP_TRY(hipMalloc((void**)&e->smp_keys, (size_t)g * sizeof(uint64_t)));
         HIP_TRY(hipMalloc((void**)&e->smp_vis, vb));
         HIP_TRY(hipMalloc((void**)&e->smp_pi, (size_t)g * hw * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&e->smp_mv, (size_t)g * sizeof(int32_t)));
         e->smp_cap = g;
     }
     HIP_TRY(hipMemcpyAsync(e->smp_vis, visits_host, vb, hipMemcpyHostToDevice, e->stream));
+    if (keys_host)
+        HIP_TRY(hipMemcpyAsync(e->smp_keys, keys_host, (size_t)g * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(apz::root_sample_kernel, dim3(g), dim3(64), 0, e->stream, e->smp_vis, e->smp_pi, e->smp_mv, g,
-                       (int)hw, 1.0f / temp, alpha, eps, (unsigned long long)seed, (unsigned long long)step);
+                       (int)hw, 1.0f / temp, alpha, eps, (unsigned long long)seed, (unsigned long long)step,
+                       keys_host ? (const unsigned long long*)e->smp_keys : nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pi_host, e->smp_pi, (size_t)g * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(moves_host, e->smp_mv, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));

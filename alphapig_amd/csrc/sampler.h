@@ -6,8 +6,10 @@
 //   noise ~ Dirichlet(alpha) over the root's children              mcts_alphaZero.py:200
 //   move  ~ Categorical((1-eps) * pi + eps * noise)                mcts_alphaZero.py:198-201
 // Dirichlet = normalised Gamma(alpha) draws (Marsaglia-Tsang with the alpha<1 boost), uniforms
-// from a stateless counter hash (splitmix64 of (seed, step, game, lane, draw)), so a given
-// (seed, step, game) always yields the same move.  Validated statistically in
+// from a stateless counter hash (splitmix64 of (seed, row key, lane, draw)).  The row key is supplied by the
+// caller -- the self-play engine passes (global game index, ply), so a game's draws depend on nothing but the
+// seed, the game and the ply: not on the batch row, the rank or the step it happened to be sampled in (two ranks
+// with the same seed never share noise) -- or defaults to (step, row).  Validated statistically in
 // tests/test_gpu_sampler.py (pi to 1e-6 of the float64 host softmax; chi-square on move
 // frequencies; Dirichlet first and second moments).
 #pragma once
@@ -64,7 +66,7 @@ __device__ __forceinline__ float wave_excl_scan(float v, int lane) {
 __global__ __launch_bounds__(64) void root_sample_kernel(const int* __restrict__ visits, float* __restrict__ pi,
                                                          int* __restrict__ moves, int G, int HW, float inv_temp,
                                                          float alpha, float eps, unsigned long long seed,
-                                                         unsigned long long step) {
+                                                         unsigned long long step, const unsigned long long* __restrict__ keys) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     const int* vrow = visits + (size_t)g * HW;
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(64) void root_sample_kernel(const int* __restrict__
     }
     s = wave_sum(s);
     const float inv = 1.0f / s;
-    HashRng rng{splitmix64(seed ^ splitmix64(step * 0x100000001B3ull + (unsigned long long)g)) + (unsigned long long)lane * 0x632BE59BD9B4E019ull, 0};
+    const unsigned long long rowkey = keys ? splitmix64(keys[g] ^ 0xA0761D6478BD642Full) : step * 0x100000001B3ull + (unsigned long long)g;
+    HashRng rng{splitmix64(seed ^ splitmix64(rowkey)) + (unsigned long long)lane * 0x632BE59BD9B4E019ull, 0};
     float nz[4], ns = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(64) void root_sample_kernel(const int* __restrict__
     }
     const float before = wave_excl_scan(ls, lane);
     const float total = __shfl(before + ls, 63);
-    // one uniform per game: hashed from (seed, step, game) only, identical in every lane
-    HashRng grng{splitmix64(seed + 0x5851F42D4C957F2Dull * (step + 1)) ^ splitmix64((unsigned long long)g + 0x9E3779B97F4A7C15ull), 0};
+    // one uniform per game: hashed from (seed, row key) only, identical in every lane
+    HashRng grng{keys ? splitmix64(seed + 0x5851F42D4C957F2Dull) ^ splitmix64(rowkey + 0x9E3779B97F4A7C15ull)
+                      : splitmix64(seed + 0x5851F42D4C957F2Dull * (step + 1)) ^ splitmix64((unsigned long long)g + 0x9E3779B97F4A7C15ull), 0};
     const float u = grng.uniform() * total;
     int pick = 0x7fffffff, last = -1;
     float c = before;

@@ -129,7 +129,10 @@ def load_model(path_or_file):
     return out
 
 
-def save_model(params, path, aux_suffixes=("_mean", "_var", "_moving_mean", "_moving_var")):
+AUX_SUFFIXES = ("_mean", "_var", "_moving_mean", "_moving_var")   # BatchNorm statistics: MXNet auxiliary states
+
+
+def save_model(params, path, aux_suffixes=AUX_SUFFIXES):
     """Write {name: array} as the reference's (arg_params, aux_params) pickle of NDArrays
     (protocol 2).  BN moving statistics go to aux_params like MXNet's Module.get_params().
     pickle only writes classes it can import, so inert `mxnet.ndarray.ndarray` module objects

@@ -102,7 +102,7 @@ class TrainPipeline(object):
         net = self.policy_value_net
         from .train import TorchTrainer
         if getattr(net, "_trainer", None) is None:
-            net._trainer = TorchTrainer(net.get_policy_param(), net.net_kind, net._n_blocks, batch_size=self.batch_size)
+            net._trainer = TorchTrainer(net.params(), net.net_kind, net._n_blocks, batch_size=self.batch_size)
         loss, entropy, kl, self.lr_multiplier = policy_update(net._trainer, mini, self.learn_rate, self.lr_multiplier,
                                                               self.epochs, self.kl_targ)
         net.set_params(net._trainer.get_params(), _keep_trainer=True)

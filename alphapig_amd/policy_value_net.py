@@ -93,11 +93,31 @@ class PolicyValueNet(object):
         self._ck(self.L.apz_load_weights(self._h, names, ptrs, sizes, len(table)))
         self._params = {name: keep[i].copy() for i, (name, _) in enumerate(table)}
 
-    def get_policy_param(self):
+    def params(self):
+        """{name: float32 array} of every parameter and BatchNorm statistic (one flat table)."""
         return dict(self._params)
 
-    def save_model(self, model_file):
-        weights.save_params(self._params, model_file)
+    def get_policy_param(self):
+        """(arg_params, aux_params) like the reference's Module.get_params()
+        (policy_value_net_mxnet.py:301-303): BatchNorm moving statistics are the aux states."""
+        from . import mxnet_model
+        arg, aux = {}, {}
+        for k, v in self._params.items():
+            (aux if k.endswith(mxnet_model.AUX_SUFFIXES) else arg)[k] = v.copy()
+        return arg, aux
+
+    def save_model(self, model_file, fmt="mxnet"):
+        """fmt 'mxnet' (default): the reference's file -- pickle protocol 2 of (arg_params, aux_params) dicts of
+        mx.nd.NDArray (policy_value_net_mxnet.py:305-309), which human_play_mxnet.py / train_mxnet.py's
+        init_model read with set_params(*model_params).  fmt 'flat': a plain {name: ndarray} pickle.
+        weights.load_params reads both."""
+        if fmt == "mxnet":
+            from . import mxnet_model
+            mxnet_model.save_model(self._params, model_file)
+        elif fmt == "flat":
+            weights.save_params(self._params, model_file)
+        else:
+            raise ValueError("fmt must be 'mxnet' or 'flat'")
 
     # ---- forward
     def forward_planes(self, planes):
@@ -173,16 +193,23 @@ class PolicyValueNet(object):
         self._ck(self.L.apz_wait(self._h, int(slot), as_ptr(probs, C.c_float), as_ptr(vals, C.c_float)))
         return probs, vals
 
-    def sample_moves(self, visits, temp=1.0, alpha=0.3, eps=0.25, seed=0, step=0):
+    def sample_moves(self, visits, temp=1.0, alpha=0.3, eps=0.25, seed=0, step=0, keys=None):
         """GPU root sampling (opt-in perf mode): visits int32 [g, HW] with -1 for non-children ->
-        (pi float32 [g, HW], moves int32 [g])."""
+        (pi float32 [g, HW], moves int32 [g]).  keys: optional uint64 [g]; row i's draw then depends on
+        (seed, keys[i]) only (not on its row or on `step`)."""
         v = np.ascontiguousarray(visits, dtype=np.int32).reshape(-1, self.hw)
         g = v.shape[0]
         pi = np.empty((g, self.hw), dtype=np.float32)
         mv = np.empty(g, dtype=np.int32)
-        self._ck(self.L.apz_sample_moves_host(self._h, as_ptr(v, C.c_int32), g, float(temp), float(alpha),
-                                              float(eps), int(seed), int(step), as_ptr(pi, C.c_float),
-                                              as_ptr(mv, C.c_int32)))
+        kp = None
+        if keys is not None:
+            k = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1)
+            if k.shape[0] != g:
+                raise ValueError("one key per row")
+            kp = as_ptr(k, C.c_uint64)
+        self._ck(self.L.apz_sample_moves_keyed_host(self._h, as_ptr(v, C.c_int32), g, float(temp), float(alpha),
+                                                    float(eps), int(seed), int(step), kp, as_ptr(pi, C.c_float),
+                                                    as_ptr(mv, C.c_int32)))
         return pi, mv
 
     # ---- reference API

@@ -154,11 +154,14 @@ class SelfPlayEngine(object):
             temps = [self._temp_for(len(self.slots[int(s)].movers)) for s in ready]
             pis = np.empty((len(ready), self.hw), dtype=np.float32)
             moves = np.empty(len(ready), dtype=np.int32)
+            # one key per row: (global game index, ply).  A game's noise then depends on the seed, the game and the
+            # ply only -- not on the batch row, the step counter or the rank (ranks share base_seed and step counters)
+            keys = np.array([(self.slots[int(s)].index << 20) | len(self.slots[int(s)].movers) for s in ready], dtype=np.uint64)
             for t in sorted(set(temps)):            # one launch per distinct temperature
                 sel = np.array([i for i, ti in enumerate(temps) if ti == t])
                 pis[sel], moves[sel] = self.evaluator.sample_moves(
                     visits[sel], temp=t, alpha=self.noise_alpha, eps=self.noise_eps,
-                    seed=self.base_seed + 7919 * int(sel[0]), step=self._sample_step)
+                    seed=self.base_seed, step=self._sample_step, keys=keys[sel])
             for pi, move, s in zip(pis, moves, ready):
                 s = int(s)
                 self._record(s, pi.astype(np.float64))

@@ -114,6 +114,13 @@ int apz_augment8(apz_engine *e, const void *planes_dev, const void *pi_dev, int 
  * (1-eps)*pi + eps*Dirichlet(alpha) (:198-201).  Deterministic in (seed, step, game index). */
 int apz_sample_moves_host(apz_engine *e, const int32_t *visits_host, int g, float temp, float alpha,
                           float eps, uint64_t seed, uint64_t step, float *pi_host, int32_t *moves_host);
+/* The same with one caller-chosen 64-bit key per row instead of (step, row): the draw of row i depends on
+ * (seed, keys_host[i]) only.  The self-play engine passes (global game index << 20 | ply), so a game's noise is
+ * reproducible whatever batch, rank or step it is sampled in (the reference's per-game reproducibility comes from
+ * np.random.seed before a game, mcts_alphaZero.py:198-201).  keys_host == NULL: as apz_sample_moves_host. */
+int apz_sample_moves_keyed_host(apz_engine *e, const int32_t *visits_host, int g, float temp, float alpha,
+                                float eps, uint64_t seed, uint64_t step, const uint64_t *keys_host,
+                                float *pi_host, int32_t *moves_host);
 
 /* ---- training-side convolution primitives (hand-written forward, data- and
  * weight-gradient of the 3x3 convolutions, callable on caller-owned dense NCHW float32 device

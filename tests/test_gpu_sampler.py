@@ -118,3 +118,31 @@ def test_engine_gpu_sampler_mode_plays_legal_games():
         assert set(np.unique(e.zs)) <= {-1.0, 0.0, 1.0}
     eng.close()
     net8.close()
+
+
+def test_keyed_draws_follow_the_game_not_the_row(net):
+    """With per-row keys (the self-play engine passes global game index << 20 | ply) a draw depends on
+    (seed, key) only: permuting the rows, changing the step counter or sampling a row alone (what another rank
+    or another batch composition would do) returns the same move for the same key -- and equal visit counts
+    under different keys (two games, or two ranks' row 0) do not share their noise."""
+    rs = np.random.RandomState(5)
+    g = 64
+    v = make_visits(rs, g)
+    keys = ((np.arange(g, dtype=np.uint64) * 7 + 3) << np.uint64(20)) | np.uint64(11)
+    pi0, mv0 = net.sample_moves(v, temp=1.0, seed=99, step=1, keys=keys)
+    perm = rs.permutation(g)
+    pi1, mv1 = net.sample_moves(v[perm], temp=1.0, seed=99, step=77, keys=keys[perm])
+    np.testing.assert_array_equal(mv1, mv0[perm])
+    np.testing.assert_array_equal(pi1, pi0[perm])
+    for i in (0, 17, 63):
+        _, one = net.sample_moves(v[i:i + 1], temp=1.0, seed=99, step=5, keys=keys[i:i + 1])
+        assert one[0] == mv0[i]
+    # identical rows, different keys: independent draws (same keys: identical)
+    same = np.repeat(v[:1], 256, axis=0)
+    k2 = (np.arange(256, dtype=np.uint64) << np.uint64(20))
+    _, a = net.sample_moves(same, temp=1.0, seed=1, step=0, keys=k2)
+    _, b = net.sample_moves(same, temp=1.0, seed=1, step=0, keys=np.zeros(256, np.uint64))
+    assert len(set(a.tolist())) > 1 and len(set(b.tolist())) == 1
+    # another seed: another stream
+    _, c = net.sample_moves(v, temp=1.0, seed=100, step=1, keys=keys)
+    assert (c != mv0).any()

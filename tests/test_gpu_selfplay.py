@@ -142,7 +142,9 @@ def test_closed_loop_selfplay_train_selfplay():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     after = net.policy_value(sb)[0]
     assert np.abs(after - before).max() > 1e-6                      # the evaluator really got new weights
-    new_prm = net.get_policy_param()
+    new_prm = net.params()
+    arg, aux = net.get_policy_param()                              # the reference's pair (policy_value_net_mxnet.py:301)
+    assert set(arg) | set(aux) == set(new_prm) and all(k.endswith(("_mean", "_var")) for k in aux)
     o = net_ref.forward(new_prm, sb, "resnet", 2, np.float64)
     np.testing.assert_allclose(after, o[1], rtol=0, atol=2e-5)
     eps2 = eng.play_games(eng.stats["games"] + 4)                   # and self-play goes on with them

@@ -52,3 +52,28 @@ def test_model_file_round_trip(tmp_path):
     np.testing.assert_array_equal(again["fc_3_1_1_weight"], prm["fc_3_1_1_weight"])
     import sys
     assert "mxnet" not in sys.modules
+
+
+def test_policy_value_net_writes_the_reference_checkpoint_layout(tmp_path):
+    """PolicyValueNet.save_model / get_policy_param (policy_value_net_mxnet.py:301-309): the file is the reference's
+    pickle of (arg_params, aux_params) NDArray dicts -- what human_play_mxnet.py and train_mxnet.py's init_model
+    unpickle and hand to set_params(*model_params) -- and it reads back into the same parameters.  (The class needs
+    a GPU to be constructed; the checkpoint methods only need its parameter table.)"""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=4, style="bench")
+    net = PolicyValueNet.__new__(PolicyValueNet)
+    net._params = {k: v.copy() for k, v in prm.items()}
+    arg, aux = net.get_policy_param()
+    assert set(aux) == {k for k in prm if k.endswith(("_mean", "_var"))} and set(arg) | set(aux) == set(prm)
+    path = str(tmp_path / "current_policy.model")
+    net.save_model(path)
+    a2, x2 = mm._Unpickler(open(path, "rb"), encoding="latin1").load()      # the pair the reference pickles
+    assert set(a2) == set(arg) and set(x2) == set(aux)
+    assert all(isinstance(v, mm.NDArray) for v in list(a2.values()) + list(x2.values()))
+    back = weights.load_params(path)
+    for k in prm:
+        np.testing.assert_array_equal(back[k], prm[k])
+    # the flat format stays readable too
+    net.save_model(str(tmp_path / "flat.model"), fmt="flat")
+    flat = weights.load_params(str(tmp_path / "flat.model"))
+    np.testing.assert_array_equal(flat["convB2_weight"], prm["convB2_weight"])
