@@ -61,7 +61,14 @@ class TorchTrainer(object):
             t = torch.tensor(np.asarray(v), dtype=self.dtype, device=self.device)
             self.p[k] = t
         self.stat_names = [k for k in self.p if k.endswith(("_mean", "_var", "_moving_mean", "_moving_var"))]
-        self.train_names = [k for k in self.p if k not in self.stat_names]
+        # gammas of the fix_gamma BatchNorm layers (every conv_act layer: res_conv1, the two 1x1 heads, and all of the
+        # simple net; policy_value_loss.json nodes 9 / 208 / 226 carry no fix_gamma=False) never enter the graph.
+        # MXNet rewrites them to 1 on every forward, so they are pinned to 1 here and kept out of the optimiser --
+        # left in, weight decay + Adam move them by ~lr per step for ever and the drift lands in saved checkpoints.
+        self.fixed_gamma_names = [k for k in self.p if k.endswith("_gamma") and not k.startswith(("bnA", "bnB"))]
+        for k in self.fixed_gamma_names:
+            self.p[k].fill_(1.0)
+        self.train_names = [k for k in self.p if k not in self.stat_names and k not in self.fixed_gamma_names]
         for k in self.train_names:
             self.p[k].requires_grad_(True)
         self.m = {k: torch.zeros_like(self.p[k]) for k in self.train_names}

@@ -5,6 +5,9 @@
             (python restatement of mcts_pure.py) vs the native host library, same seeds
   config 2  8x8, 4-in-row, n_playout=200, simple net, 64 concurrent games on the GPU
   config 3  15x15, 5-in-row, n_playout=400, 10-block residual net, 1024 concurrent games (short slice)
+  config 5  per-GPU slice of the competition-strength setting: 15x15, n_playout=1600, c_puct=5, Dirichlet 0.3,
+            temperature schedule (temp 1.0 for the first 30 plies, then 0.1: a build-side extension, the reference
+            plays at one constant temp -- SURVEY F5), 1024 concurrent games (configs 4 / 5 shard this over 8 GPUs)
 Prints one JSON object.  Run on the GPU box:  python tests/config_table.py
 (Lives under tests/: config 1 times the CPU oracle, which only tests, smoke() and bench.py's cpu_baseline may import.)
 """
@@ -55,14 +58,15 @@ def config1(n_games=4):
     return out
 
 
-def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10):
+def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None):
     from alphapig_amd.policy_value_net import PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
     prm = weights.init_params(kind, w, w, 9, n_blocks, 128, seed=0, style="bench")
     net = PolicyValueNet(w, w, batch_size=max(16, G // 2), n_blocks=n_blocks, n_filter=128, model_params=prm,
                          net_kind=kind)
     eng = SelfPlayEngine(net, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=77, pipeline=2,
-                         forced_opening=(w == 15))
+                         forced_opening=(w == 15), temp_schedule=temp_schedule)
+    info0 = eng.pool.pool_info()
     eng.run_steps(30)
     net.sync()
     l0, m0, g0, p0 = eng.stats["leaf_evals"], eng.stats["moves"], eng.stats["games"], eng.stats["plies"]
@@ -72,7 +76,9 @@ def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10):
     dt = time.perf_counter() - t
     res = {"concurrent_games": G, "steps": steps, "leaf_evals_per_s": (eng.stats["leaf_evals"] - l0) / dt,
            "moves_per_s": (eng.stats["moves"] - m0) / dt, "games_finished": eng.stats["games"] - g0,
-           "ms_per_step": 1e3 * dt / steps}
+           "ms_per_step": 1e3 * dt / steps, "host_tree_s": eng.timers["host_s"], "evaluator_s": eng.timers["eval_s"],
+           "tree_arena_gb": info0["arena_bytes"] / 1e9, "tree_arena_pretouched": info0["pretouched"],
+           "peak_tree_nodes": eng.pool.pool_info()["peak_nodes"]}
     if eng.stats["games"] - g0 > 0:
         res["mean_plies_finished"] = (eng.stats["plies"] - p0) / (eng.stats["games"] - g0)
         res["games_per_s_finished"] = (eng.stats["games"] - g0) / dt
@@ -85,6 +91,8 @@ def main():
     out = {"config1_pure_mcts_8x8_n100_cpu": config1()}
     out["config2_simple_net_8x8_n200_64games"] = gpu_config("simple", 8, 4, 200, 64, 6000)
     out["config3_resnet10_15x15_n400_1024games"] = gpu_config("resnet", 15, 5, 400, 1024, 400)
+    out["config5_slice_resnet10_15x15_n1600_1024games"] = gpu_config("resnet", 15, 5, 1600, 1024, 2000,
+                                                                     temp_schedule=[(0, 1.0), (30, 0.1)])
     print(json.dumps(out, indent=1))
 
 

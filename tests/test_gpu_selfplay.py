@@ -182,3 +182,67 @@ def test_rccl_collectives_world_size_1():
     r = subprocess.run([sys.executable, os.path.join(here, "_rccl_worker.py")], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "rccl world_size=1 ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_arena_on_gpu_equals_sequential_oracle_on_recorded_outputs():
+    """SURVEY 8f rank 3 on the GPU: `policy_evaluate` (train_mxnet.py:242-263 -> Game.start_play, game.py:204-230)
+    as M concurrent matches through the HIP evaluator.  The evaluator outputs the GPU produced are recorded and
+    replayed into the sequential oracle players (RefMCTSPlayer in play mode against RefPureMCTSPlayer, one legacy
+    MT19937 stream per match as after np.random.seed(base + i)): every match must come out move for move."""
+    from alphapig_amd.arena import Arena, win_ratio
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    from oracle.mcts_ref import RefPureMCTSPlayer
+    w, nrow, npl, pure_n, base, n = 15, 5, 40, 30, 4242, 6
+    prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=6, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=prm)
+    rec = Recorder(net)
+    res = Arena(rec, w, w, nrow, n_playout=npl, pure_mcts_playout_num=pure_n, base_seed=base, n_threads=4,
+                max_concurrent=4).play(n)                                   # two blocks: 4 + 2 matches
+    assert [r.index for r in res] == list(range(n)) and len(rec.table) > 0
+    stride = 240
+    fn = replay_fn(rec.table, stride)
+    for r in res:
+        b = RefBoard(w, w, nrow)
+        b.init_board(r.index % 2)
+        rs = np.random.RandomState(base + r.index)
+        players = {1: RefMCTSPlayer(fn, 5, npl, 0, rng=rs), 2: RefPureMCTSPlayer(5, pure_n, rng=rs)}
+        while True:
+            b.do_move(int(players[b.get_current_player()].get_action(b)))
+            end, winner = b.game_end()
+            if end:
+                break
+        assert list(r.moves) == list(b.move_list), r.index
+        assert r.winner == winner
+    assert 0.0 <= win_ratio(res) <= 1.0
+    net.close()
+
+
+def test_config5_slice_1024_games_n_playout_1600():
+    """BASELINE config 5's per-GPU slice (mcts_alphaZero.py:147-149 with n_playout = 1600; 1024 concurrent games,
+    10-block net, temperature schedule): a few hundred scheduler rounds at full size.  Size-independent properties:
+    every round evaluates one leaf per active game, playouts are conserved (net evaluations + terminal playouts =
+    rounds), no game moves before its 1600 playouts are done, the move that is then played is a legal root child,
+    the tree arenas were pre-touched (31 GB: the memory-aware limit, not the old 16 GB cliff) and no tree outgrew
+    its reservation."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    G, npl, rounds = 1024, 1600, 1640
+    prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=G // 2, n_blocks=10, n_filter=128, model_params=prm)
+    eng = SelfPlayEngine(net, 15, 15, 5, n_games=G, n_playout=npl, c_puct=5, temp=1.0, base_seed=555, pipeline=2,
+                         temp_schedule=[(0, 1.0), (30, 0.1)])
+    info = eng.pool.pool_info()
+    assert info["arena_bytes"] > 25e9 and info["pretouched"]
+    leafs = eng.run_steps(1500)
+    assert leafs == G * 1500                                        # one evaluated leaf per game and round
+    assert eng.stats["moves"] <= G // 100                           # (a move before round 1600 needs terminal-leaf playouts)
+    leafs += eng.run_steps(rounds - 1500)                          # crosses the first searched move of every game
+    assert leafs == G * rounds and eng.stats["moves"] >= G
+    for s in range(0, G, 97):
+        mv, _ = eng.pool.history(s)
+        assert len(mv) >= 1 and len(set(mv.tolist())) == len(mv)    # legal: no cell played twice
+        st = eng.pool.stats(s)
+        assert st["net_evals"] == rounds and st["net_evals"] + st["terminal_playouts"] >= npl
+    cap = (npl + 8) * 226 * 5 // 4
+    assert eng.pool.pool_info()["peak_nodes"] <= cap
+    eng.close()
+    net.close()

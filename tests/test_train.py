@@ -62,6 +62,11 @@ def test_adam_update_rule():
     # moving statistics moved towards the batch statistics, trainable tensors only in train_names
     assert not np.allclose(tr.get_params()["bnA1_moving_mean"], prm["bnA1_moving_mean"])
     assert "bnA1_moving_mean" not in tr.train_names
+    # gammas of the fix_gamma layers are not optimised and read 1, as MXNet leaves them (it rewrites them on forward)
+    out = tr.get_params()
+    for k in ("res_conv1_gamma", "conv3_1_1_gamma", "conv3_2_1_gamma"):
+        assert k not in tr.train_names and np.all(out[k] == 1.0)
+    assert "bnA1_gamma" in tr.train_names and "bnB1_gamma" in tr.train_names
 
 
 def test_policy_update_reduces_loss_and_adapts_lr():
