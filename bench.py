@@ -79,7 +79,7 @@ def _cpu_worker(budget_s):
     while time.perf_counter() - t0 < budget_s:
         mcts.playout(b.clone())
         n += 1
-    return n, time.perf_counter() - t0
+    return n, time.perf_counter() - t0, net.isa
 
 
 def cpu_baseline(mean_plies, cores, budget_s=15.0):
@@ -89,24 +89,31 @@ def cpu_baseline(mean_plies, cores, budget_s=15.0):
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO) for _ in range(cores)]
-    total_n, rates = 0, []
+    total_n, rates, isa = 0, [], None
     for p in procs:
         out, _ = p.communicate()
         try:
             r = json.loads(out.decode().strip().splitlines()[-1])
             total_n += r["n"]
             rates.append(r["n"] / r["dt"])
+            isa = r.get("isa", isa)
         except (ValueError, IndexError, KeyError):
             pass
     if not rates:                      # no child came back: measure in-process on one core
-        n, dt = _cpu_worker(budget_s)
+        n, dt, isa = _cpu_worker(budget_s)
         total_n, rates = n, [n / dt]
     leaf_s = sum(rates)
+    cpu = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {"value": leaf_s / (N_PLAYOUT * mean_plies), "unit": "games/s", "cores": len(rates), "kind": "port",
-            "leaf_evals_per_s": leaf_s, "leaf_evals_per_s_per_core": leaf_s / len(rates),
-            "sample": "%d sequential playouts in %d independent 15x15 self-play searches, one process per core (oracle tree + "
-                      "oracle/net_ref.c batch-1 forward), %.0f s each; games/s = leaf-evals/s / (400 * mean plies)"
-                      % (total_n, len(rates), budget_s)}
+            "leaf_evals_per_s": leaf_s, "leaf_evals_per_s_per_core": leaf_s / len(rates), "cpu": cpu, "net_isa": isa,
+            "sample": "%d sequential playouts in %d independent 15x15 self-play searches, one single-threaded process per core "
+                      "(oracle tree + oracle/net_ref.c batch-1 forward per playout: vectorised direct convolution, %s), "
+                      "%.0f s each; games/s = leaf-evals/s / (400 * mean plies)" % (total_n, len(rates), isa, budget_s)}
 
 
 def stem_roofline(device):
@@ -207,8 +214,8 @@ def main():
                          "8 games per rank); the JSON line is marked invalid and is NOT a measurement")
     args = ap.parse_args()
     if args.cpu_worker > 0:
-        n_, dt_ = _cpu_worker(args.cpu_worker)
-        print(json.dumps({"n": n_, "dt": dt_}))
+        n_, dt_, isa_ = _cpu_worker(args.cpu_worker)
+        print(json.dumps({"n": n_, "dt": dt_, "isa": isa_}))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

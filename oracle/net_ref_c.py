@@ -24,7 +24,7 @@ def pack_params(prm, n_blocks):
 
 
 class CNet(object):
-    def __init__(self, prm, height, width, c_in=9, n_filter=128, n_blocks=10):
+    def __init__(self, prm, height, width, c_in=9, n_filter=128, n_blocks=10, fast=True):
         if not os.path.exists(LIB):
             raise RuntimeError("%s missing: run `python -m alphapig_amd.build oracle`" % LIB)
         self.L = C.CDLL(LIB)
@@ -33,6 +33,20 @@ class CNet(object):
         self.L.ref_net_forward.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp]
         self.H, self.W, self.C, self.F, self.nb = height, width, c_in, n_filter, n_blocks
         self.blob = pack_params(prm, n_blocks)
+        # vectorised forward (AVX-512 or AVX2+FMA, picked at run time); None -> plain loops
+        self.L.ref_fast_create.restype = C.c_void_p
+        self.L.ref_fast_create.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        self.L.ref_fast_forward.restype = C.c_int
+        self.L.ref_fast_forward.argtypes = [C.c_void_p, fp, fp, fp, fp, fp]
+        self.L.ref_fast_destroy.argtypes = [C.c_void_p]
+        self.L.ref_fast_isa.argtypes = [C.c_void_p]
+        self.fast = self.L.ref_fast_create(self.blob.ctypes.data_as(fp), c_in, n_filter, n_blocks, height, width) if fast else None
+        self.isa = {0: "plain C loops", 1: "AVX2+FMA", 2: "AVX-512"}[self.L.ref_fast_isa(self.fast) if self.fast else 0]
+
+    def __del__(self):
+        if getattr(self, "fast", None):
+            self.L.ref_fast_destroy(self.fast)
+            self.fast = None
 
     def forward_one(self, planes):
         x = np.ascontiguousarray(planes, dtype=np.float32).reshape(self.C, self.H, self.W)
@@ -42,9 +56,13 @@ class CNet(object):
         logits = np.empty(hw, np.float32)
         vlogit = np.empty(1, np.float32)
         fp = C.POINTER(C.c_float)
-        rc = self.L.ref_net_forward(self.blob.ctypes.data_as(fp), self.C, self.F, self.nb, self.H, self.W,
-                                    x.ctypes.data_as(fp), probs.ctypes.data_as(fp), value.ctypes.data_as(fp),
-                                    logits.ctypes.data_as(fp), vlogit.ctypes.data_as(fp))
+        if self.fast:
+            rc = self.L.ref_fast_forward(self.fast, x.ctypes.data_as(fp), probs.ctypes.data_as(fp), value.ctypes.data_as(fp),
+                                         logits.ctypes.data_as(fp), vlogit.ctypes.data_as(fp))
+        else:
+            rc = self.L.ref_net_forward(self.blob.ctypes.data_as(fp), self.C, self.F, self.nb, self.H, self.W,
+                                        x.ctypes.data_as(fp), probs.ctypes.data_as(fp), value.ctypes.data_as(fp),
+                                        logits.ctypes.data_as(fp), vlogit.ctypes.data_as(fp))
         if rc != 0:
             raise MemoryError("ref_net_forward failed")
         return logits, probs, vlogit, value

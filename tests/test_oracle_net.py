@@ -20,16 +20,20 @@ def test_c_port_matches_numpy_oracle():
     build.build_oracle()
     from oracle.net_ref_c import CNet
     prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=3, style="bench")
-    net = CNet(prm, 15, 15, 9, 128, 2)
     rs = np.random.RandomState(0)
     planes = (rs.rand(3, 9, 15, 15) > 0.7).astype(np.float32)
     o = net_ref.forward(prm, planes, "resnet", 2, np.float64)
-    for i in range(3):
-        lg, pr, vl, v = net.forward_one(planes[i])
-        np.testing.assert_allclose(lg, o[0][i], rtol=0, atol=1e-4)
-        np.testing.assert_allclose(pr, o[1][i], rtol=0, atol=2e-5)
-        np.testing.assert_allclose(vl, o[2][i], rtol=0, atol=1e-4)
-        np.testing.assert_allclose(v, o[3][i], rtol=0, atol=2e-5)
+    # both implementations in oracle/net_ref.c: the plain loops and the vectorised forward the CPU baseline times
+    # (AVX-512 / AVX2+FMA at run time; on a CPU with neither `fast` silently is the plain one)
+    for fast in (False, True):
+        net = CNet(prm, 15, 15, 9, 128, 2, fast=fast)
+        assert (net.isa == "plain C loops") == (not fast) or not fast
+        for i in range(3):
+            lg, pr, vl, v = net.forward_one(planes[i])
+            np.testing.assert_allclose(lg, o[0][i], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(pr, o[1][i], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(vl, o[2][i], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(v, o[3][i], rtol=0, atol=2e-5)
 
 
 def test_fix_gamma_semantics():
