@@ -26,6 +26,8 @@
 
 namespace {
 
+typedef std::lock_guard<std::recursive_mutex> EngineLock;
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
@@ -96,7 +98,11 @@ struct apz_engine {
         int n = 0;
         bool busy = false;
     } slots[APZ_MAX_SLOTS];
-    std::mutex submit_lock;
+    // One lock for everything that touches the engine's buffers, stream, weights or timing state.  Recursive: the
+    // public entry points call each other (apz_forward_codes_host -> _async -> apz_encode_planes).  The pipeline
+    // workers of SelfPlayEngine submit from their own threads while the main thread may call policy_value_fn,
+    // set_params or the arena -- every such call now queues behind the submissions instead of racing them.
+    std::recursive_mutex submit_lock;
     bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
     int act_ps = 0, act_rs = 0;
     bool lds_attr_set[16] = {false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done, per kernel variant
@@ -119,6 +125,7 @@ struct apz_engine {
     int trunk_kernel = 3;   // 0: trunk15_ring_kernel (direct), 1: trunk15_wino_kernel, 2: trunk15_wino2_kernel,
                             // 3: trunk15_wino3_kernel (APZ_TRUNK_KERNEL=ring|wino|wino2|wino3)
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
+    bool wino3_prefetch = true;   // trunk15_wino3_kernel warms L2 with the next layer's weights (APZ_WINO3_PREFETCH=0: off)
     // profiling
     bool profiling = false;
     int prof_stride = 1, prof_phase = 0;   // time every prof_stride-th forward only
@@ -356,6 +363,13 @@ int launch_trunk_wino2(apz_engine* e, const ConvLayer& L, const float* in, const
 }
 
 int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    // the layer that runs next (the first trunk layer after the last): its packed weights are prefetched into L2
+    const float* next = nullptr;
+    if (e->wino3_prefetch) {
+        const size_t li = (size_t)(&L - &e->convs[0]);
+        const ConvLayer& N = e->convs[li + 1 < e->convs.size() ? li + 1 : 1];
+        next = N.upk2;
+    }
     using T = apz::Wino3;
     bool& configured = e->lds_attr_set[6];
     if (!configured) {
@@ -368,10 +382,10 @@ int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const
     const int grid = std::min((n + 1) / 2, e->num_cu);   // one persistent workgroup per CU; item = board pair x channel half
     if (resid)
         hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n);
+                           L.bias, resid, out, n, next);
     else
         hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n);
+                           L.bias, resid, out, n, next);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -623,6 +637,7 @@ apz_engine* apz_create(const apz_config* cfg) {
     if (const char* tk = getenv("APZ_TRUNK_KERNEL"))
         e->trunk_kernel = std::string(tk) == "ring" ? 0 : std::string(tk) == "wino" ? 1 : std::string(tk) == "wino2" ? 2 : 3;
     if (const char* tw = getenv("APZ_TRUNK_WAVES")) e->trunk_waves = (atoi(tw) == 8) ? 8 : 4;
+    if (const char* pf = getenv("APZ_WINO3_PREFETCH")) e->wino3_prefetch = atoi(pf) != 0;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
     const size_t B = cfg->max_batch, hw = e->hw;
@@ -668,6 +683,7 @@ int64_t apz_param_size(apz_engine* e, int i) {
 
 int apz_load_weights(apz_engine* e, const char* const* names, const float* const* ptrs, const int64_t* sizes, int n) {
     if (!e || !names || !ptrs || !sizes) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     std::map<std::string, const float*> P;
     std::map<std::string, int64_t> S;
@@ -783,6 +799,7 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
 int apz_forward(apz_engine* e, const void* planes_dev, int n, void* probs_dev, void* values_dev, void* logits_dev,
                 void* vlogits_dev) {
     if (!e || !planes_dev || !probs_dev || !values_dev) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     return forward_dev(e, (const float*)planes_dev, n, (float*)probs_dev, (float*)values_dev, (float*)logits_dev,
                        (float*)vlogits_dev);
@@ -790,6 +807,7 @@ int apz_forward(apz_engine* e, const void* planes_dev, int n, void* probs_dev, v
 
 int apz_forward_host(apz_engine* e, const float* planes_host, int n, float* probs_host, float* values_host) {
     if (!e || !planes_host || !probs_host || !values_host) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
     if (n == 0) return APZ_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -810,6 +828,7 @@ int apz_forward_host(apz_engine* e, const float* planes_host, int n, float* prob
 int apz_forward_codes_async(apz_engine* e, const uint8_t* codes_pinned, int n, float* probs_pinned,
                             float* values_pinned) {
     if (!e || !codes_pinned || !probs_pinned || !values_pinned) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
     if (e->cfg.c_in != 9 && e->cfg.c_in != 4) return fail(APZ_E_STATE, "bad c_in");
     if (n == 0) return APZ_OK;
@@ -827,6 +846,7 @@ int apz_forward_codes_async(apz_engine* e, const uint8_t* codes_pinned, int n, f
 
 int apz_forward_codes_host(apz_engine* e, const uint8_t* codes_host, int n, float* probs_host, float* values_host) {
     if (!e || !codes_host || !probs_host || !values_host) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
     if (n == 0) return APZ_OK;
     std::memcpy(e->h_codes, codes_host, (size_t)n * e->code_stride);
@@ -843,7 +863,7 @@ int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) 
     if (!e || !codes_host) return fail(APZ_E_ARG, "null argument");
     if (slot < 0 || slot >= APZ_MAX_SLOTS) return fail(APZ_E_ARG, "slot out of range");
     if (n < 1 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch must be in [1, max_batch]");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     apz_engine::Slot& sl = e->slots[slot];
     if (sl.busy) return fail(APZ_E_STATE, "slot still in flight: call apz_wait first");
@@ -874,6 +894,8 @@ int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) 
 
 int apz_wait(apz_engine* e, int slot, float* probs_host, float* values_host) {
     if (!e || !probs_host || !values_host) return fail(APZ_E_ARG, "null argument");
+    // (no engine lock: a slot is owned by the one thread that submitted into it, and holding the lock across the
+    // event wait would stop the other pipeline groups from submitting behind this batch)
     if (slot < 0 || slot >= APZ_MAX_SLOTS) return fail(APZ_E_ARG, "slot out of range");
     apz_engine::Slot& sl = e->slots[slot];
     if (!sl.busy) return fail(APZ_E_STATE, "nothing submitted in this slot");
@@ -900,6 +922,7 @@ void apz_host_free(void* p) {
 
 int apz_encode_planes(apz_engine* e, const void* codes_dev, int n, int n_planes, void* planes_dev) {
     if (!e || !codes_dev || !planes_dev) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     if (n_planes != 9 && n_planes != 4) return fail(APZ_E_ARG, "n_planes must be 9 or 4");
     if (n <= 0) return APZ_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -915,6 +938,7 @@ int apz_encode_planes(apz_engine* e, const void* codes_dev, int n, int n_planes,
 int apz_augment8(apz_engine* e, const void* planes_dev, const void* pi_dev, int n, int c, void* planes_out_dev,
                  void* pi_out_dev) {
     if (!e || !planes_dev || !pi_dev || !planes_out_dev || !pi_out_dev) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     if (!e->perm_s) return fail(APZ_E_UNSUPPORTED, "augmentation needs a square board");
     if (n <= 0) return APZ_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -937,7 +961,7 @@ int apz_sample_moves_keyed_host(apz_engine* e, const int32_t* visits_host, int g
     if (!e || !visits_host || !pi_host || !moves_host) return fail(APZ_E_ARG, "null argument");
     if (g < 1 || e->hw > 256 || !(temp > 0.f) || !(alpha > 0.f) || eps < 0.f || eps > 1.f)
         return fail(APZ_E_ARG, "bad sampler arguments");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t hw = e->hw, vb = (size_t)g * hw * sizeof(int32_t);
     if ((size_t)g > e->smp_cap) {
@@ -986,7 +1010,7 @@ int apz_conv3x3_pack(apz_engine* e, const void* w_dev, int cin, int cout, int tr
     if (!e || !w_dev || !wpk_dev || cin < 1 || cout < 1) return fail(APZ_E_ARG, "bad argument");
     const int co_p = transpose_flip ? cin : cout;
     if (co_p % 16) return fail(APZ_E_UNSUPPORTED, "packed C_out must be a multiple of 16");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     const long total = apz_conv3x3_packed_size(transpose_flip ? cout : cin, co_p);
@@ -1001,7 +1025,7 @@ int apz_conv3x3_fwd(apz_engine* e, const void* x_dev, const void* wpk_dev, const
     if (!e || !x_dev || !wpk_dev || !y_dev || n < 1 || cin_p < 1) return fail(APZ_E_ARG, "bad argument");
     if (cout_p != 64 && cout_p != 128 && cout_p != 256)
         return fail(APZ_E_UNSUPPORTED, "conv3x3_fwd: C_out must be 64, 128 or 256");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (!e->zeros256) {
         HIP_TRY(hipMalloc((void**)&e->zeros256, 256 * sizeof(float)));
@@ -1039,7 +1063,7 @@ int64_t apz_wino_packed_size(void) { return (int64_t)apz::Wino2::UPK_FLOATS; }
 
 int apz_wino_pack(apz_engine* e, const void* w_dev, int transpose_flip, void* upk_dev, void* stream) {
     if (!e || !w_dev || !upk_dev) return fail(APZ_E_ARG, "bad argument");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     hipLaunchKernelGGL(apz::pack_wino2_kernel, dim3(8 * 2 * 32 * 64 / 256), dim3(256), 0, e->stream, (const float*)w_dev,
@@ -1052,7 +1076,7 @@ int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const v
                   int layout, void* stream) {
     if (!e || !x_dev || !upk_dev || !y_dev || n < 1 || layout < 0 || layout > 1) return fail(APZ_E_ARG, "bad argument");
     if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wino_conv: 15x15 boards only");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (!e->zeros256) {
         HIP_TRY(hipMalloc((void**)&e->zeros256, 256 * sizeof(float)));
@@ -1106,7 +1130,7 @@ int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void
         return fail(APZ_E_ARG, "bad argument (C_out must be a multiple of 32)");
     if (layout == APZ_LAYOUT_ROWS16 && (e->cfg.height != 15 || e->cfg.width != 15))
         return fail(APZ_E_UNSUPPORTED, "padded-row layout: 15x15 boards only");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     HIP_TRY(hipMemsetAsync(dw_dev, 0, (size_t)cout * cin * 9 * sizeof(float), e->stream));
@@ -1176,7 +1200,7 @@ int apz_bn_fwd(apz_engine* e, const void* x_dev, const void* resid_dev, const vo
         return fail(APZ_E_ARG, "bad argument");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     if (int rc = bn_sums(e)) return rc;
@@ -1213,7 +1237,7 @@ int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void*
         return fail(APZ_E_ARG, "bad argument");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     if (int rc = bn_sums(e)) return rc;
@@ -1247,7 +1271,7 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     if (!e || !x_dev || !dy_dev || !dw_dev || n < 1) return fail(APZ_E_ARG, "bad argument");
     if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wgrad_wino: 15x15 boards only");
     using T = apz::WgradWino;
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     const int slices = std::max(1, std::min(n, e->num_cu / T::GROUPS));       // 12 position groups x slices ~ one per CU
@@ -1278,7 +1302,7 @@ int apz_adam_step(apz_engine* e, const void* table_host, int ntensors, float lr_
                   float rescale, void* stream) {
     if (!e || !table_host || ntensors < 1 || ntensors > 4096) return fail(APZ_E_ARG, "bad argument");
     static_assert(sizeof(apz::AdamTensor) == 48, "apz_adam_tensor layout");
-    std::lock_guard<std::mutex> guard(e->submit_lock);
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     const size_t bytes = (size_t)ntensors * sizeof(apz::AdamTensor);
@@ -1300,6 +1324,7 @@ int apz_adam_step(apz_engine* e, const void* table_host, int ntensors, float lr_
 
 int apz_sync(apz_engine* e) {
     if (!e) return fail(APZ_E_ARG, "null engine");
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     resolve_pending(e);
@@ -1342,6 +1367,7 @@ int apz_memcpy_d2h(apz_engine* e, void* dst_host, const void* src_dev, int64_t b
 
 int apz_conv3x3_bench(apz_engine* e, int layer, int n, int iters, int warmup, float* ms_out) {
     if (!e || !ms_out) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     if (!e->loaded) return fail(APZ_E_STATE, "weights not loaded");
     if (layer < 0 || layer >= (int)e->convs.size() || n < 1 || n > e->cfg.max_batch || iters < 1 || warmup < 0)
         return fail(APZ_E_ARG, "bad layer / batch / iteration count");
@@ -1384,6 +1410,7 @@ int apz_conv3x3_bench(apz_engine* e, int layer, int n, int iters, int warmup, fl
 
 int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
     if (!e || !host_out) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
     if (!e->loaded || e->last_n < 1) return fail(APZ_E_STATE, "run a forward first");
     if (layer < 0 || layer >= (int)e->convs.size()) return fail(APZ_E_ARG, "bad layer");
     const int64_t need = (int64_t)e->last_n * e->convs[layer].cout * e->hw;
@@ -1412,6 +1439,7 @@ int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
 
 int apz_set_profiling(apz_engine* e, int on) {
     if (!e) return fail(APZ_E_ARG, "null engine");
+    EngineLock guard(e->submit_lock);
     HIP_TRY(hipStreamSynchronize(e->stream));
     resolve_pending(e);
     e->profiling = on != 0;
@@ -1426,6 +1454,7 @@ int apz_set_profiling(apz_engine* e, int on) {
 
 int apz_kernel_time_ms(apz_engine* e, int kernel_class, float* out2) {
     if (!e || !out2 || kernel_class < 0 || kernel_class >= APZ_K_COUNT) return fail(APZ_E_ARG, "bad argument");
+    EngineLock guard(e->submit_lock);
     out2[0] = (float)e->k_ms[kernel_class];
     out2[1] = (float)e->k_cnt[kernel_class];
     return APZ_OK;
