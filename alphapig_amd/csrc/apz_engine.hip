@@ -125,7 +125,6 @@ struct apz_engine {
     int trunk_kernel = 3;   // 0: trunk15_ring_kernel (direct), 1: trunk15_wino_kernel, 2: trunk15_wino2_kernel,
                             // 3: trunk15_wino3_kernel (APZ_TRUNK_KERNEL=ring|wino|wino2|wino3)
     int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
-    bool wino3_prefetch = true;   // trunk15_wino3_kernel warms L2 with the next layer's weights (APZ_WINO3_PREFETCH=0: off)
     // profiling
     bool profiling = false;
     int prof_stride = 1, prof_phase = 0;   // time every prof_stride-th forward only
@@ -363,13 +362,6 @@ int launch_trunk_wino2(apz_engine* e, const ConvLayer& L, const float* in, const
 }
 
 int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    // the layer that runs next (the first trunk layer after the last): its packed weights are prefetched into L2
-    const float* next = nullptr;
-    if (e->wino3_prefetch) {
-        const size_t li = (size_t)(&L - &e->convs[0]);
-        const ConvLayer& N = e->convs[li + 1 < e->convs.size() ? li + 1 : 1];
-        next = N.upk2;
-    }
     using T = apz::Wino3;
     bool& configured = e->lds_attr_set[6];
     if (!configured) {
@@ -382,10 +374,10 @@ int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const
     const int grid = std::min((n + 1) / 2, e->num_cu);   // one persistent workgroup per CU; item = board pair x channel half
     if (resid)
         hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n, next);
+                           L.bias, resid, out, n);
     else
         hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n, next);
+                           L.bias, resid, out, n);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -637,7 +629,6 @@ apz_engine* apz_create(const apz_config* cfg) {
     if (const char* tk = getenv("APZ_TRUNK_KERNEL"))
         e->trunk_kernel = std::string(tk) == "ring" ? 0 : std::string(tk) == "wino" ? 1 : std::string(tk) == "wino2" ? 2 : 3;
     if (const char* tw = getenv("APZ_TRUNK_WAVES")) e->trunk_waves = (atoi(tw) == 8) ? 8 : 4;
-    if (const char* pf = getenv("APZ_WINO3_PREFETCH")) e->wino3_prefetch = atoi(pf) != 0;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
     const size_t B = cfg->max_batch, hw = e->hw;

@@ -87,7 +87,7 @@ template <bool RESID, bool RELU = true>
 __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restrict__ in, const float* __restrict__ upk,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out,
-                                                            int n, const float* __restrict__ upk_next) {
+                                                            int n) {
     using T = Wino3;
 #ifdef APZ_WINO3_STAMPS
     // phases: 0 prologue, 1 barrier wait, 2 chunk body (staging + transform + MFMA); epilogue: 3 compute, 4 barrier waits,
@@ -511,27 +511,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         run(std::integral_constant<int, 0>{});
     else
         run(std::integral_constant<int, 1>{});
-    // ---- warm this XCD's L2 with the NEXT layer's weights (upk_next; may be null).  A forward walks 20 layers with
-    // 2.6 MB of packed weights each; by the time a layer comes round again its weights have left the XCD's 4 MB L2
-    // (and the Infinity Cache, which the activations fill), so every launch would start its weight ring on cold
-    // misses that the ring (one k-step ahead) cannot cover.  One dword per 128-byte line, 1/32 of the buffer per
-    // workgroup of an XCD (blocks b and b + 8 share one; a different placement only changes which L2 gets warm),
-    // issued after the last store and never waited for: the loads are hidden from the compiler, their destination
-    // register is dead.
-    if (upk_next) {
-        const unsigned slice = (unsigned)((blockIdx.x >> 3) & 31);
-        const unsigned lines = (unsigned)(Wino2::UPK_FLOATS * 4 / 128);           // 20480
-        const unsigned per = (lines + 31) / 32;                                    // lines per workgroup (640)
-#pragma unroll
-        for (unsigned k = 0; k < 2; k++) {
-            const unsigned ln = slice * per + k * 512 + (unsigned)tid;
-            if (k * 512 + (unsigned)tid < per && ln < lines) {
-                const char* ptr = reinterpret_cast<const char*>(upk_next) + (size_t)ln * 128;
-                float sink;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(ptr) : "memory");
-            }
-        }
-    }
 #ifdef APZ_WINO3_STAMPS
     st_acc[7] = __builtin_readcyclecounter() - st_t0;
     if (lane == 0 && blockIdx.x < 4)

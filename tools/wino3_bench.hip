@@ -100,10 +100,10 @@ int main(int argc, char** argv) {
             CK(hipMemset(out2, 0xff, (size_t)n * 128 * 240 * 4));
             if (resid) {
                 hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out2, n);
-                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n, (const float*)nullptr);
+                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
             } else {
                 hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out2, n);
-                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n, (const float*)nullptr);
+                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
             }
             CK(hipDeviceSynchronize());
 #ifdef APZ3_DEBUG_X
@@ -198,8 +198,8 @@ int main(int argc, char** argv) {
                     if (resid) hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out, n);
                     else hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out, n);
                 } else {
-                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n, (const float*)nullptr);
-                    else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n, (const float*)nullptr);
+                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                    else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
                 }
             };
             for (int i = 0; i < 5; i++) launch();
@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
 #ifdef APZ_WINO3_STAMPS
     {
         const int n = 512, grid = 256;
-        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n, (const float*)nullptr);
+        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
         CK(hipDeviceSynchronize());
         unsigned long long hst[4 * 8 * 8];
         CK(hipMemcpyFromSymbol(hst, HIP_SYMBOL(apz::apz_wino3_stamps), sizeof(hst)));
