@@ -115,10 +115,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     const int q = lane >> 4, j = lane & 15;
     const int ct = wave & 3;
 
-    for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 2048) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef APZ3_POISON
-    for (int i = tid; i < T::STAGE_FLOATS; i += 512) stg[i] = 777.f;
-#endif
 
     // ---- work items of this workgroup.  Item = (board pair, channel half h).
     // Grids that are a multiple of 16 run in "duo" mode: two workgroups that the dispatcher (observed: round-robin
@@ -296,6 +292,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         raw_fetch(0);
         const f32x4 r0 = rg[0], r1 = rg[1];
         raw_fetch(1);
+        // zero halo of both raw buffers, while the first planes are on their way
+        for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 2048) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                        // zero fill done
         raw_store(1);
         rg[0] = r0;

@@ -131,8 +131,13 @@ def stem_roofline(device):
         net.forward_planes(planes)
         ms = net.conv_bench(0, n, iters=50, warmup=10)
         alg = n * (c_in * H * W + N_FILTER * H * W) * 4 + N_FILTER * c_in * 9 * 4
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r02_stem_traffic.json")
+        if os.path.exists(tpath):                      # PMC passes of rocprofv3 on tools/stem_profile.py (same launches)
+            with open(tpath) as f:
+                traffic = json.load(f).get("c_in_%d" % c_in, {}).get("traffic_bytes_per_launch")
         out["c_in_%d" % c_in] = {"bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "us_per_launch": ms * 1e3,
+                                 "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "us_per_launch": ms * 1e3,
                                  "shape": "%dx%dx15x15 -> 128 ch" % (n, c_in), "algorithmic_bytes": alg,
                                  "tflops": 2.0 * n * c_in * 9 * N_FILTER * H * W / ms / 1e9}
         net.close()
