@@ -33,7 +33,7 @@
 // raw (LDS): as wino2 ([2 boards x 8 channels] planes, row stride 20, plane stride 340, zero halo).
 // V (LDS): [pp 18][board 2][ch 8][tile 16][2]: pp = position pair (row i, columns 2kp, 2kp+1) = 3i + kp;
 //      the B operands of positions 2pp, 2pp+1 are one conflict-free ds_read_b64, no padding.
-// X (LDS, inside V[1], which is idle during an epilogue): [wave 8][3][lane 64][4].
+// X (LDS, inside V[1], which is idle during an epilogue): [wave 8][12 values][lane 64].
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -391,24 +391,33 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         float* sw = stg + wave * (4 * T::SPLANE);
         const int s_own = eq * T::SPLANE + (4 * ety) * T::SROW + 4 * etx;       // this lane's 4x4 patch (row a: + a*SROW)
         const int s_lin = (le >> 2) * T::SROW + (le & 3) * 4;                   // plane piece `lane` (row lane>>2, quarter lane&3)
-        float* xw_own = xb + wave * T::XW + le * 4;
-        const float* xw_oth = xb + (wave ^ 4) * T::XW + le * 4;
         const f32x4 bv = bload(r_bias, (unsigned)(eq * 16), (unsigned)(cot * 64));
         const unsigned ep_vo = le < 60 ? le * 16 : 0x80000000u;                 // piece `lane` of a plane; lanes 60..63 out of range
         const unsigned st_out_vo = ((ph == 0) || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch: stores dropped
         auto plane_so = [&](int r, int qp) {                                    // plane q' of step r
             return (unsigned)__builtin_amdgcn_readfirstlane(bd_own * T::C + cot * 16 + qp * 4 + r) * plane_b;
         };
-        auto partial = [&](const f32x4* a, int r, f32x4* p) {   // rows of this wave -> (P0, P1, P2)
-            float hh[3][4];
+        // rows of this wave -> (P0, P1, P2) for TWO channels at once: components r0, r0 + 1 of an accumulator are
+        // neighbouring registers, so the whole k-direction transform (wino2_at6's formulas) and the row sums run as
+        // packed two-wide operations -- half the VALU instructions of the epilogue's biggest part
+        auto partial2 = [&](const f32x4* a, auto R0, f32x2 (*p)[4]) {
+            constexpr int r0 = decltype(R0)::value;
+            f32x2 hh[3][4];
 #pragma unroll
-            for (int ii = 0; ii < 3; ii++)
-                wino2_at6(a[ii * 6 + 0][r], a[ii * 6 + 1][r], a[ii * 6 + 2][r], a[ii * 6 + 3][r], a[ii * 6 + 4][r],
-                          a[ii * 6 + 5][r], hh[ii]);
+            for (int ii = 0; ii < 3; ii++) {
+                f32x2 m[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) m[k] = __builtin_shufflevector(a[ii * 6 + k], a[ii * 6 + k], r0, r0 + 1);
+                const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                hh[ii][0] = (m[0] + s12) + s34;
+                hh[ii][1] = fma2(2.f, d34, d12);
+                hh[ii][2] = fma2(4.f, s34, s12);
+                hh[ii][3] = fma2(8.f, d34, d12) + m[5];
+            }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 if (ph == 0) {
-                    const float s12 = hh[1][e] + hh[2][e];
+                    const f32x2 s12 = hh[1][e] + hh[2][e];
                     p[0][e] = hh[0][e] + s12;
                     p[1][e] = hh[1][e] - hh[2][e];
                     p[2][e] = s12;
@@ -426,35 +435,34 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #pragma unroll
                 for (int qp = 0; qp < 4; qp++) winb[r & 1][qp] = bload(r_res, ep_vo, plane_so(r, qp));
             };
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                f32x4 ps[3];
-                partial(acc[1 - own], r, ps);
+            // X (one float per lane and value: [12][64]; any register can be stored, no packing moves)
+            float* xs = xb + wave * T::XW + le;
+            const float* xr = xb + (wave ^ 4) * T::XW + le;
+            auto step = [&](int r, int sub, f32x2 (*qs)[4], f32x2 (*qo)[4]) {
                 APZ3_STAMP(3)
                 __syncthreads();                // r = 0: every wave's MFMAs over V[1] are done; r > 0: X of step r-1 consumed
                 APZ3_STAMP(4)
 #pragma unroll
-                for (int v = 0; v < 3; v++) *reinterpret_cast<f32x4*>(xw_own + v * 256) = ps[v];
-                // residual planes of step 0: only now -- at the top of the epilogue all 144 accumulators are live and
-                // 16 more registers in flight spill; the planes of step 1 follow after this step's second partial, those
-                // of steps 2, 3 here, one step ahead.  Always BEFORE the step's stores: vmcnt counts in issue order, so
-                // the wait for these loads leaves the stores in flight instead of draining them.
-                if (RESID && r >= 1 && r + 1 < 4) resid_load(r + 1);   // ~one step ahead of its use
-                if (RESID && r == 0) resid_load(0);
+                for (int v = 0; v < 3; v++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) xs[(v * 4 + e) * 64] = qs[v][e][sub];
+                // Residual planes: steps 0 and 1 only now -- at the top of the epilogue all 144 accumulators are live
+                // and registers in flight would spill -- steps 2, 3 one step ahead.  Always BEFORE the step's stores:
+                // vmcnt counts in issue order, so the wait for these loads leaves the stores in flight.
+                if (RESID && r == 0) {
+                    resid_load(0);
+                    resid_load(1);
+                }
+                if (RESID && r >= 1 && r + 1 < 4) resid_load(r + 1);
                 f32x4 (&win)[4] = winb[r & 1];
-#ifdef APZ3_DEBUG_X
-                if (blockIdx.x == 0 && t == 0)
-                    *reinterpret_cast<f32x4*>(&apz_wino3_dbg[(((wave * 4 + r) * 2 + 0) * 64 + lane) * 4]) = ps[2];
-#endif
-                f32x4 po[3];
-                partial(acc[own], r, po);
-                if (RESID && r == 0) resid_load(1);     // (both boards' r = 0 accumulator components are dead now)
                 APZ3_STAMP(3)
                 __syncthreads();                // X of step r complete
                 APZ3_STAMP(4)
-                f32x4 px[3];
+                float px[3][4];
 #pragma unroll
-                for (int v = 0; v < 3; v++) px[v] = *reinterpret_cast<const f32x4*>(xw_oth + v * 256);
+                for (int v = 0; v < 3; v++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) px[v][e] = xr[(v * 4 + e) * 64];
                 f32x4 w4[4];
                 if (RESID) {                    // plane pieces -> staging -> this lane's 4x4 patch
 #pragma unroll
@@ -468,18 +476,19 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #endif
                     APZ3_STAMP(5)
                 }
-#ifdef APZ3_DEBUG_X
-                if (blockIdx.x == 0 && t == 0)
-                    *reinterpret_cast<f32x4*>(&apz_wino3_dbg[(((wave * 4 + r) * 2 + 1) * 64 + lane) * 4]) = px[2];
-#endif
-                const f32x4* lo = own == 0 ? po : px;
-                const f32x4* hi = own == 0 ? px : po;
-                f32x4 y[4];
-                y[0] = lo[0] + hi[0];
-                y[1] = lo[1] + 2.f * hi[1];
-                y[2] = lo[2] + 4.f * hi[0];
-                y[3] = lo[1] + (8.f * hi[1] + hi[2]);
                 const float bvr = bv[r];
+                f32x4 y[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float lo0 = own == 0 ? qo[0][e][sub] : px[0][e], lo1 = own == 0 ? qo[1][e][sub] : px[1][e],
+                                lo2 = own == 0 ? qo[2][e][sub] : px[2][e];
+                    const float hi0 = own == 0 ? px[0][e] : qo[0][e][sub], hi1 = own == 0 ? px[1][e] : qo[1][e][sub],
+                                hi2 = own == 0 ? px[2][e] : qo[2][e][sub];
+                    y[0][e] = lo0 + hi0;
+                    y[1][e] = __builtin_fmaf(2.f, hi1, lo1);
+                    y[2][e] = __builtin_fmaf(4.f, hi0, lo2);
+                    y[3][e] = lo1 + __builtin_fmaf(8.f, hi1, hi2);
+                }
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
                     f32x4 v = y[a] + bvr;
@@ -494,12 +503,24 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #pragma unroll
                 for (int qp = 0; qp < 4; qp++) pv[qp] = *reinterpret_cast<const f32x4*>(sw + qp * T::SPLANE + s_lin);
                 APZ3_FENCE();
-                // next step's residual planes BEFORE this step's stores: vmcnt counts in issue order, so the wait for
-                // these loads then leaves the four stores in flight instead of draining them
                 APZ3_STAMP(3)
 #pragma unroll
                 for (int qp = 0; qp < 4; qp++)
                     bstore(r_out, st_out_vo, plane_so(r, qp), pv[qp]);
+            };
+            {
+                f32x2 qs[3][4], qo[3][4];
+                partial2(acc[1 - own], std::integral_constant<int, 0>{}, qs);
+                partial2(acc[own], std::integral_constant<int, 0>{}, qo);
+                step(0, 0, qs, qo);
+                step(1, 1, qs, qo);
+            }
+            {
+                f32x2 qs[3][4], qo[3][4];
+                partial2(acc[1 - own], std::integral_constant<int, 2>{}, qs);
+                partial2(acc[own], std::integral_constant<int, 2>{}, qo);
+                step(2, 0, qs, qo);
+                step(3, 1, qs, qo);
             }
         }
         APZ3_STAMP(6)
