@@ -109,7 +109,9 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_forward_host", "apz_forward_codes_host", "apz_forward_codes_async", "apz_submit_codes", "apz_wait", "apz_host_alloc",
                "apz_host_free", "apz_encode_planes", "apz_augment8", "apz_sample_moves_host", "apz_sample_moves_keyed_host", "apz_conv3x3_packed_size", "apz_conv3x3_pack",
                "apz_conv3x3_fwd", "apz_conv3x3_wgrad", "apz_wino_packed_size", "apz_wino_pack", "apz_wino_conv",
-               "apz_bn_fwd", "apz_bn_bwd", "apz_adam_step", "apz_wgrad_wino",
+               "apz_wino_conv_add", "apz_bn_fwd", "apz_bn_bwd", "apz_adam_step", "apz_wgrad_wino",
+               "apz_conv1x1_fwd", "apz_conv1x1_bwd", "apz_fc_fwd", "apz_fc_bwd", "apz_dropout", "apz_pv_loss",
+               "apz_layout_convert", "apz_bias_grad", "apz_add",
                "apz_sync", "apz_stream",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
                "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms"]
@@ -160,6 +162,16 @@ def hip():
         "apz_bn_bwd": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "apz_wgrad_wino": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
         "apz_adam_step": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+        "apz_wino_conv_add": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_conv1x1_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_conv1x1_bwd": (C.c_int, [vp] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_fc_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_fc_bwd": (C.c_int, [vp] * 7 + [C.c_int, C.c_int, C.c_int, vp]),
+        "apz_dropout": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, vp]),
+        "apz_pv_loss": (C.c_int, [vp] * 5 + [C.c_int] + [vp] * 6),
+        "apz_layout_convert": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
+        "apz_bias_grad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_add": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
         "apz_sync": (C.c_int, [vp]),
         "apz_stream": (vp, [vp]),
         "apz_device_alloc": (vp, [vp, C.c_int64]),

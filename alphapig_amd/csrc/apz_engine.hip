@@ -23,6 +23,7 @@
 #include "wgrad_wino.h"
 #include "sampler.h"
 #include "conv_train.h"
+#include "heads_train.h"
 
 namespace {
 
@@ -105,7 +106,7 @@ struct apz_engine {
     std::recursive_mutex submit_lock;
     bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
     int act_ps = 0, act_rs = 0;
-    bool lds_attr_set[16] = {false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done, per kernel variant
+    bool lds_attr_set[32] = {false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done, per kernel variant
     int conv_lds_set[16] = {0};
     // persistent sampler staging (apz_sample_moves_host)
     int32_t* smp_vis = nullptr;
@@ -116,6 +117,8 @@ struct apz_engine {
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     double* bn_sums = nullptr;                     // apz_bn_fwd / _bwd: per-channel reduction scratch
     float* wgw_scratch = nullptr;                  // apz_wgrad_wino: partial dU per batch slice
+    float* head_scratch = nullptr;                 // apz_conv1x1_bwd / apz_pv_loss: per-board partial sums
+    size_t head_scratch_floats = 0;
     int wgw_slices = 0;
     void* adam_tab = nullptr;                      // apz_adam_step: device copy of the tensor table
     size_t adam_cap = 0;
@@ -565,7 +568,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch};
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -1063,10 +1066,11 @@ int apz_wino_pack(apz_engine* e, const void* w_dev, int transpose_flip, void* up
     return APZ_OK;
 }
 
-int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, void* y_dev, int n, int relu,
-                  int layout, void* stream) {
+int apz_wino_conv_add(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, const void* resid_dev,
+                      void* y_dev, int n, int relu, int layout, void* stream) {
     if (!e || !x_dev || !upk_dev || !y_dev || n < 1 || layout < 0 || layout > 1) return fail(APZ_E_ARG, "bad argument");
     if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wino_conv: 15x15 boards only");
+    if (resid_dev && layout != APZ_LAYOUT_ROWS16) return fail(APZ_E_UNSUPPORTED, "wino_conv: residual input in the padded-row layout only");
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (!e->zeros256) {
@@ -1083,15 +1087,6 @@ int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const v
         }
         e->wino_scratch_boards = n;
     }
-    using T = apz::Wino2;
-    bool& configured = e->lds_attr_set[7];
-    if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<false, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<false, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        configured = true;
-    }
     const long planes = (long)n * 128;
     const int cgrid = (int)std::min<long>((planes * 240 + 255) / 256, 16384);
     const bool dense = layout == APZ_LAYOUT_DENSE;
@@ -1101,18 +1096,44 @@ int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const v
         hipLaunchKernelGGL(apz::rows16_from_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, (const float*)x_dev,
                            e->wino_scratch[0], planes);
     const float* b = bias_dev ? (const float*)bias_dev : e->zeros256;
+    const float* rs = (const float*)resid_dev;
     const int grid = std::min((n + 1) / 2, e->num_cu);
-    if (relu)
-        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, xin,
-                           (const float*)upk_dev, b, nullptr, yout, n);
-    else
-        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false, false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, xin,
-                           (const float*)upk_dev, b, nullptr, yout, n);
+    // the self-play path's kernel (csrc/trunk15_wino3.h); it addresses activations through 32-bit buffer offsets, so
+    // batches of >= 2^31 / (128 * 960) boards take its predecessor
+    const bool k3 = (long long)n * 128 * 960 < (1ll << 31);
+#define APZ_WINO_TRAIN(KERNEL, LDS, SLOT, RESID, RELU)                                                                       \
+    do {                                                                                                                     \
+        bool& configured = e->lds_attr_set[SLOT];                                                                            \
+        if (!configured) {                                                                                                   \
+            HIP_TRY(hipFuncSetAttribute((const void*)apz::KERNEL<RESID, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                        LDS));                                                                               \
+            configured = true;                                                                                               \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((apz::KERNEL<RESID, RELU>), dim3(grid), dim3(512), LDS, e->stream, xin, (const float*)upk_dev, b, \
+                           rs, yout, n);                                                                                     \
+    } while (0)
+    if (k3) {
+        if (rs && relu) APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 16, true, true);
+        else if (rs) APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 17, true, false);
+        else if (relu) APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 18, false, true);
+        else APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 19, false, false);
+    } else {
+        if (rs && relu) APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 20, true, true);
+        else if (rs) APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 21, true, false);
+        else if (relu) APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 22, false, true);
+        else APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 23, false, false);
+    }
+#undef APZ_WINO_TRAIN
     if (dense)
         hipLaunchKernelGGL(apz::rows16_to_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, e->wino_scratch[1],
                            (float*)y_dev, planes);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
+}
+
+int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, void* y_dev, int n, int relu,
+                  int layout, void* stream) {
+    return apz_wino_conv_add(e, x_dev, upk_dev, bias_dev, nullptr, y_dev, n, relu, layout, stream);
 }
 
 int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, int cin, int cout,
@@ -1303,12 +1324,175 @@ int apz_adam_step(apz_engine* e, const void* table_host, int ntensors, float lr_
         HIP_TRY(hipMalloc((void**)&e->adam_tab, bytes));
         e->adam_cap = bytes;
     }
-    // the table buffer of the previous step may still be read by its kernel: wait for it, then a SYNCHRONOUS copy (the
-    // caller's host buffer need not outlive this call; 6 KB)
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->adam_tab, table_host, bytes, hipMemcpyHostToDevice));
+    // Stream-ordered upload: the copy queues behind the previous step's kernel (which read the same device table), and
+    // for pageable host memory hipMemcpyAsync returns once the 6 KB have been staged, so the caller's buffer need
+    // not outlive the call.  (No stream synchronisation: the optimiser step no longer drains the GPU.)
+    HIP_TRY(hipMemcpyAsync(e->adam_tab, table_host, bytes, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(apz::adam_step_kernel, dim3(32, ntensors), dim3(256), 0, e->stream,
                        (const apz::AdamTensor*)e->adam_tab, lr_t, b1, b2, eps, rescale);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+// ---- heads and loss of the training graph (csrc/heads_train.h)
+namespace {
+int head_scratch(apz_engine* e, size_t floats) {
+    if (floats > e->head_scratch_floats) {
+        if (e->head_scratch) HIP_TRY(hipFree(e->head_scratch));
+        e->head_scratch = nullptr;
+        HIP_TRY(hipMalloc((void**)&e->head_scratch, floats * sizeof(float)));
+        e->head_scratch_floats = floats;
+    }
+    return APZ_OK;
+}
+}  // namespace
+
+int apz_conv1x1_fwd(apz_engine* e, const void* x_dev, const void* w_dev, const void* bias_dev, void* y_dev, int n, int C,
+                    int CO, int layout, void* stream) {
+    if (!e || !x_dev || !w_dev || !y_dev || n < 1 || C < 1 || C > 1024 || CO < 1 || CO > 8) return fail(APZ_E_ARG, "bad argument");
+    int ps, rs;
+    if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    hipLaunchKernelGGL(apz::conv1x1_fwd_kernel, dim3(n), dim3(256), (size_t)CO * C * sizeof(float), e->stream,
+                       (const float*)x_dev, (const float*)w_dev, (const float*)bias_dev, (float*)y_dev, C, CO, e->cfg.height,
+                       e->cfg.width, ps, rs);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_conv1x1_bwd(apz_engine* e, const void* x_dev, const void* w_dev, const void* dy_dev, void* dx_dev, void* dw_dev,
+                    void* db_dev, int n, int C, int CO, int layout, int accumulate_dx, void* stream) {
+    if (!e || !x_dev || !w_dev || !dy_dev || !dw_dev || n < 1 || C < 1 || C > 1024 || CO < 1 || CO > 8)
+        return fail(APZ_E_ARG, "bad argument");
+    int ps, rs;
+    if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    const int P = e->cfg.height * e->cfg.width;
+    if (int rc = head_scratch(e, (size_t)n * CO * C)) return rc;
+    const size_t lds = ((size_t)CO * C + (size_t)CO * P + 8 * 128) * sizeof(float);
+    hipLaunchKernelGGL(apz::conv1x1_bwd_kernel, dim3(n), dim3(256), lds, e->stream, (const float*)x_dev, (const float*)w_dev,
+                       (const float*)dy_dev, (float*)dx_dev, e->head_scratch, C, CO, e->cfg.height, e->cfg.width, ps, rs,
+                       accumulate_dx);
+    hipLaunchKernelGGL(apz::colsum_kernel, dim3((CO * C + 255) / 256), dim3(256), 0, e->stream, (const float*)e->head_scratch,
+                       (float*)dw_dev, n, CO * C, 1.0f);
+    HIP_TRY(hipGetLastError());
+    if (db_dev) return apz_bias_grad(e, dy_dev, db_dev, n, CO, APZ_LAYOUT_DENSE, stream);
+    return APZ_OK;
+}
+
+int apz_bias_grad(apz_engine* e, const void* dy_dev, void* db_dev, int n, int C, int layout, void* stream) {
+    if (!e || !dy_dev || !db_dev || n < 1 || C < 1) return fail(APZ_E_ARG, "bad argument");
+    int ps, rs;
+    if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    const int slices = std::max(1, std::min(n, (e->num_cu * 8 + C - 1) / C));
+    if (int rc = head_scratch(e, (size_t)slices * C)) return rc;
+    hipLaunchKernelGGL(apz::bias_grad_kernel, dim3(C, slices), dim3(256), 0, e->stream, (const float*)dy_dev, e->head_scratch, n, C,
+                       ps);
+    hipLaunchKernelGGL(apz::colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, e->stream, (const float*)e->head_scratch,
+                       (float*)db_dev, slices, C, 1.0f);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_add(apz_engine* e, void* y_dev, const void* x_dev, int64_t count, void* stream) {
+    if (!e || !y_dev || !x_dev || count < 1) return fail(APZ_E_ARG, "bad argument");
+    if (((uintptr_t)y_dev | (uintptr_t)x_dev) & 15) return fail(APZ_E_ARG, "add: 16-byte aligned tensors");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    const long n4 = count / 4;
+    hipLaunchKernelGGL(apz::add_inplace_kernel, dim3((int)std::max<long>(1, std::min<long>((n4 + 255) / 256, 8192))), dim3(256), 0,
+                       e->stream, (float*)y_dev, (const float*)x_dev, n4, (long)count);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_fc_fwd(apz_engine* e, const void* x_dev, const void* w_dev, const void* bias_dev, void* y_dev, int n, int K, int N,
+               void* stream) {
+    if (!e || !x_dev || !w_dev || !y_dev || n < 1 || K < 1 || N < 1) return fail(APZ_E_ARG, "bad argument");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    // y[n][N] = x[n][K] W[N][K]^T + b:  A = x (row stride K), B(k, j) = W[j][k]
+    hipLaunchKernelGGL(apz::sgemm_mfma_kernel, dim3((N + 63) / 64, (n + 63) / 64), dim3(256), 0, e->stream, (const float*)x_dev,
+                       (const float*)w_dev, (const float*)bias_dev, (float*)y_dev, n, N, K, (long)K, 1L, 1L, (long)K, N);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_fc_bwd(apz_engine* e, const void* x_dev, const void* w_dev, const void* dy_dev, void* dx_dev, void* dw_dev, void* db_dev,
+               int n, int K, int N, void* stream) {
+    if (!e || !x_dev || !w_dev || !dy_dev || n < 1 || K < 1 || N < 1) return fail(APZ_E_ARG, "bad argument");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    if (dx_dev)     // dx[n][K] = dy[n][N] W[N][K]
+        hipLaunchKernelGGL(apz::sgemm_mfma_kernel, dim3((K + 63) / 64, (n + 63) / 64), dim3(256), 0, e->stream,
+                           (const float*)dy_dev, (const float*)w_dev, (const float*)nullptr, (float*)dx_dev, n, K, N, (long)N, 1L,
+                           (long)K, 1L, K);
+    if (dw_dev)     // dW[N][K] = dy^T[N][n] x[n][K]:  A(m, k) = dy[k][m]
+        hipLaunchKernelGGL(apz::sgemm_mfma_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, e->stream,
+                           (const float*)dy_dev, (const float*)x_dev, (const float*)nullptr, (float*)dw_dev, N, K, n, 1L, (long)N,
+                           (long)K, 1L, K);
+    if (db_dev)
+        hipLaunchKernelGGL(apz::colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, e->stream, (const float*)dy_dev, (float*)db_dev,
+                           n, N, 1.0f);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_dropout(apz_engine* e, const void* x_dev, void* y_dev, int64_t count, float keep, uint64_t seed, uint64_t step,
+                void* stream) {
+    if (!e || !x_dev || !y_dev || count < 1 || !(keep > 0.f) || keep > 1.f) return fail(APZ_E_ARG, "bad argument");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    hipLaunchKernelGGL(apz::dropout_kernel, dim3((int)std::min<int64_t>((count + 255) / 256, 4096)), dim3(256), 0, e->stream,
+                       (const float*)x_dev, (float*)y_dev, (long)count, keep, (unsigned long long)seed, (unsigned long long)step);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_pv_loss(apz_engine* e, const void* logits_dev, const void* vlogit_dev, const void* pi_dev, const void* z_dev, int n,
+                void* loss3_dev, void* dlogits_dev, void* dvlogit_dev, void* probs_dev, void* values_dev, void* stream) {
+    if (!e || !logits_dev || !vlogit_dev || n < 1) return fail(APZ_E_ARG, "bad argument");
+    if ((loss3_dev || dlogits_dev || dvlogit_dev) && (!pi_dev || !z_dev)) return fail(APZ_E_ARG, "targets missing");
+    if (e->hw > 4096) return fail(APZ_E_UNSUPPORTED, "board too large");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    if (int rc = head_scratch(e, (size_t)n * 3)) return rc;
+    hipLaunchKernelGGL(apz::pv_loss_kernel, dim3((n + 3) / 4), dim3(256), 0, e->stream, (const float*)logits_dev,
+                       (const float*)vlogit_dev, (const float*)pi_dev, (const float*)z_dev, n, e->hw, 1.0f / (float)n,
+                       loss3_dev ? e->head_scratch : (float*)nullptr, (float*)dlogits_dev, (float*)dvlogit_dev, (float*)probs_dev,
+                       (float*)values_dev);
+    if (loss3_dev)  // (value loss, policy loss, entropy): batch means, samples summed in index order
+        hipLaunchKernelGGL(apz::colsum_kernel, dim3(1), dim3(256), 0, e->stream, (const float*)e->head_scratch, (float*)loss3_dev, n,
+                           3, 1.0f / (float)n);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_layout_convert(apz_engine* e, const void* src_dev, void* dst_dev, int64_t planes, int to_rows16, void* stream) {
+    if (!e || !src_dev || !dst_dev || planes < 1) return fail(APZ_E_ARG, "bad argument");
+    if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "padded-row layout: 15x15 boards only");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    const int grid = (int)std::min<int64_t>((planes * 240 + 255) / 256, 16384);
+    if (to_rows16)
+        hipLaunchKernelGGL(apz::rows16_from_dense_kernel, dim3(grid), dim3(256), 0, e->stream, (const float*)src_dev, (float*)dst_dev,
+                           (long)planes);
+    else
+        hipLaunchKernelGGL(apz::rows16_to_dense_kernel, dim3(grid), dim3(256), 0, e->stream, (const float*)src_dev, (float*)dst_dev,
+                           (long)planes);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }

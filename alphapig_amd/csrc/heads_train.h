@@ -1,0 +1,246 @@
+// Training-side kernels for everything in the reference's loss graph that is not a 3x3 convolution or a
+// BatchNorm (policy_value_net_mxnet.py:85-102, :173-193): the two 1x1 head convolutions, the two FullyConnected
+// layers (as one fp32-MFMA GEMM kernel), Dropout(0.5), and the loss
+//   mean((z - tanh(u))^2) + mean(-sum(pi * log softmax(logits)))   with the entropy monitor mean(sum(-p log p)),
+// forward and backward.  gfx950 only.  (3x3 convolutions: conv3x3_mfma.h / trunk15_wino2.h / conv_train.h /
+// wgrad_wino.h; BatchNorm and Adam: conv_train.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv3x3_mfma.h"
+#include "sampler.h"
+
+namespace apz {
+
+// ---- 1x1 convolution, C_in -> CO (CO <= 8), over n boards of P = H*W pixels.
+// x / dx: planes with plane stride ps and row stride rs (dense: ps = P, rs = W; padded rows: 240 / 16); y / dy dense
+// [n][CO][P].  One workgroup per board; the weights (CO x C floats) sit in LDS.
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                          int CO, int H, int W, int ps, int rs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CO][C]
+    const int P = H * W, n = blockIdx.x;
+    for (int i = threadIdx.x; i < CO * C; i += 256) lds[i] = w[i];
+    __syncthreads();
+    const float* xb = x + (size_t)n * C * ps;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const int off = (p / W) * rs + (p % W);
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; o++) acc[o] = (o < CO && bias) ? bias[o] : 0.f;
+        for (int c = 0; c < C; c++) {
+            const float v = xb[(size_t)c * ps + off];
+#pragma unroll
+            for (int o = 0; o < 8; o++)
+                if (o < CO) acc[o] = __builtin_fmaf(lds[o * C + c], v, acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            if (o < CO) y[((size_t)n * CO + o) * P + p] = acc[o];
+    }
+}
+
+// backward: dx[n][c][p] = sum_o w[o][c] dy[n][o][p]  (written in x's layout, pad cells zero; `accumulate`: added to
+//           what dx holds -- the two heads share one input gradient),
+//           part[n][o][c] = sum_p dy[n][o][p] x[n][c][p]  (per-board partial of dw; summed over n in a fixed order by
+//           colsum_kernel below: no float atomics, results do not depend on arrival order).
+__global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ part, int C, int CO, int H, int W, int ps,
+                                                          int rs, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CO][C] weights, [CO][P] dy
+    const int P = H * W, n = blockIdx.x;
+    float* wl = lds;
+    float* dl = lds + CO * C;
+    for (int i = threadIdx.x; i < CO * C; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < CO * P; i += 256) dl[i] = dy[(size_t)n * CO * P + i];
+    __syncthreads();
+    const float* xb = x + (size_t)n * C * ps;
+    if (dx) {
+        float* dxb = dx + (size_t)n * C * ps;
+        const int cells = H * rs;                 // cells of a plane, pad cells included (cells <= ps)
+        for (int i = threadIdx.x; i < C * cells; i += 256) {
+            const int c = i / cells, q = i - c * cells, row = q / rs, col = q - row * rs;
+            float s = 0.f;
+            if (col < W) {
+                const int p = row * W + col;
+#pragma unroll
+                for (int o = 0; o < 8; o++)
+                    if (o < CO) s = __builtin_fmaf(wl[o * C + c], dl[o * P + p], s);
+                if (accumulate) s += dxb[(size_t)c * ps + q];
+            }
+            dxb[(size_t)c * ps + q] = s;
+        }
+    }
+    // dw partials: thread (c, half) sums over its half of the pixels; the two halves meet through LDS
+    const int c = threadIdx.x % 128, half = threadIdx.x / 128;
+    for (int c0 = 0; c0 < C; c0 += 128) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c0 + c < C) {
+            const float* xc = xb + (size_t)(c0 + c) * ps;
+            for (int p = half; p < P; p += 2) {
+                const float v = xc[(p / W) * rs + (p % W)];
+#pragma unroll
+                for (int o = 0; o < 8; o++)
+                    if (o < CO) acc[o] = __builtin_fmaf(dl[o * P + p], v, acc[o]);
+            }
+        }
+        __syncthreads();
+        float* ex = lds + CO * C + CO * P;        // [8][128] exchange
+        if (half == 1)
+#pragma unroll
+            for (int o = 0; o < 8; o++) ex[o * 128 + c] = acc[o];
+        __syncthreads();
+        if (half == 0 && c0 + c < C)
+#pragma unroll
+            for (int o = 0; o < 8; o++)
+                if (o < CO) part[((size_t)n * CO + o) * C + c0 + c] = acc[o] + ex[o * 128 + c];
+    }
+}
+
+// out[j] = sum_i in[i][j] over `rows` rows of `cols` floats, rows summed in index order (deterministic);
+// used for dw of the 1x1 convolutions (rows = boards), bias gradients (rows = batch) and the loss terms.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
+                                                     float scale) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    double s = 0.0;
+    for (int i = 0; i < rows; i++) s += (double)in[(size_t)i * cols + j];
+    out[j] = (float)(s * (double)scale);
+}
+
+// part[s][c] = sum over the boards of slice s and the cells of plane c of dy[n][c][.] (planes of `ps` floats: dense, or
+// padded rows whose pad cells are zero); grid (C, slices); colsum_kernel then adds the slices in index order.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ part, int n, int C,
+                                                        int ps) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, slices = gridDim.y, sl = blockIdx.y;
+    const int b0 = (int)((long)n * sl / slices), b1 = (int)((long)n * (sl + 1) / slices);
+    double s = 0.0;
+    for (int b = b0; b < b1; b++) {
+        const float* pl = dy + ((size_t)b * C + c) * ps;
+        float t = 0.f;
+        for (int i = threadIdx.x; i < ps; i += 256) t += pl[i];
+        s += (double)t;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)sl * C + c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// y += x
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long n4, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        float4 a = ((const float4*)y)[i];
+        const float4 b = ((const float4*)x)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        ((float4*)y)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] += x[n4 * 4 + threadIdx.x];
+}
+
+// ---- C[M][N] = sum_k A(m, k) B(k, n) (+ bias[n]) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 FMA
+// chains).  A(m, k) = a[m * a_rs + k * a_cs], B(k, n) = b[k * b_rs + n * b_cs]: the strides express the three products
+// of a FullyConnected layer (y = x W^T + b;  dx = dy W;  dW = dy^T x) without transposed copies.
+// A workgroup (4 waves) owns a 64 x 64 tile of C; wave w its rows 16w..16w+15, four 16 x 16 MFMA tiles wide.
+// The matrices here are small (<= 512 x 900 x 900: 0.2-0.8 GFLOP per product), operands are read straight from
+// global memory / L2 per k-step.
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ bias, float* __restrict__ c, int M, int N,
+                                                         int K, long a_rs, long a_cs, long b_rs, long b_cs, int ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 64;
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool mrow = m0 + r < M;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kq;
+        const float av = (mrow && k < K) ? a[(long)(m0 + r) * a_rs + (long)k * a_cs] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int nn = n0 + t * 16 + r;
+            const float bv = (nn < N && k < K) ? b[(long)k * b_rs + (long)nn * b_cs] : 0.f;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+        }
+    }
+    // D layout: column = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int nn = n0 + t * 16 + r;
+        if (nn >= N) continue;
+        const float bb = bias ? bias[nn] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int mm = m0 + 4 * kq + g;
+            if (mm < M) c[(size_t)mm * ldc + nn] = acc[t][g] + bb;
+        }
+    }
+}
+
+// ---- Dropout (policy_value_net_mxnet.py:88,95: p = 0.5 on both flattened head inputs in training mode).  The keep mask
+// is a stateless hash of (seed, step, element index): the backward pass regenerates it instead of storing it.
+// y = x * keep_mask / keep   (forward and backward are the same map)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float keep,
+                                                      unsigned long long seed, unsigned long long step) {
+    const float inv = 1.0f / keep;
+    const unsigned long long key = splitmix64(seed ^ splitmix64(step + 0x2545F4914F6CDD1Dull));
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const unsigned long long h = splitmix64(key + (unsigned long long)i * 0x9E3779B97F4A7C15ull);
+        const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+        y[i] = u < keep ? x[i] * inv : 0.f;
+    }
+}
+
+// ---- loss (policy_value_net_mxnet.py:180-193), one wavefront per sample:
+//   p = softmax(logits), v = tanh(u);   terms[i] = ((z - v)^2, -sum_j pi_j log p_j, -sum_j p_j log p_j)
+//   dlogits = (p * sum_j pi_j - pi) * gscale,   du = 2 (v - z) (1 - v^2) * gscale        (gscale = 1 / batch: the means)
+// probs / values (may be NULL) get p and v (the inference outputs of the same forward).
+__global__ __launch_bounds__(256) void pv_loss_kernel(const float* __restrict__ logits, const float* __restrict__ u,
+                                                      const float* __restrict__ pi, const float* __restrict__ z, int n, int HW,
+                                                      float gscale, float* __restrict__ terms, float* __restrict__ dlogits,
+                                                      float* __restrict__ du, float* __restrict__ probs, float* __restrict__ values) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* lr = logits + (size_t)i * HW;
+    float m = -INFINITY;
+    for (int j = lane; j < HW; j += 64) m = fmaxf(m, lr[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < HW; j += 64) s += expf(lr[j] - m);
+    s = wave_sum(s);
+    const float logs = logf(s);
+    float ce = 0.f, ent = 0.f, spi = 0.f;
+    for (int j = lane; j < HW; j += 64) {
+        const float lp = lr[j] - m - logs, p = expf(lp);
+        const float t = pi ? pi[(size_t)i * HW + j] : 0.f;
+        ce -= t * lp;
+        ent -= p * lp;
+        spi += t;
+        if (probs) probs[(size_t)i * HW + j] = p;
+    }
+    ce = wave_sum(ce);
+    ent = wave_sum(ent);
+    spi = wave_sum(spi);
+    if (dlogits)
+        for (int j = lane; j < HW; j += 64) {
+            const float p = expf(lr[j] - m - logs);
+            dlogits[(size_t)i * HW + j] = (p * spi - pi[(size_t)i * HW + j]) * gscale;
+        }
+    if (lane == 0) {
+        const float v = tanhf(u[i]);
+        if (values) values[i] = v;
+        if (terms) {
+            const float d = (z ? z[i] : 0.f) - v;
+            terms[(size_t)i * 3 + 0] = d * d;
+            terms[(size_t)i * 3 + 1] = ce;
+            terms[(size_t)i * 3 + 2] = ent;
+        }
+        if (du) du[i] = 2.f * (v - z[i]) * (1.f - v * v) * gscale;
+    }
+}
+
+}  // namespace apz

@@ -1,11 +1,13 @@
-"""3x3 convolution for the training graph on the hand-written HIP kernels:
-forward, data gradient and weight gradient through include/alphapig_hip.h
-(apz_conv3x3_pack / _fwd / _wgrad), wrapped as a torch.autograd.Function so that the rest of the
-interim training graph (BatchNorm, ReLU, heads, loss: small element-wise work) can stay in
-PyTorch while ~97 % of the training FLOPs run on this repository's kernels.
+"""The training graph's operators on the hand-written HIP kernels, one thin function per
+C-ABI entry point of include/alphapig_hip.h: 3x3 convolution forward / data gradient / weight gradient (direct MFMA
+kernel, or the self-play path's fused Winograd kernel for the 128 -> 128 trunk shape), bias gradient, training-mode
+BatchNorm (+ residual) (+ ReLU) forward and backward, the 1x1 head convolutions, FullyConnected, Dropout, the
+policy-value loss, layout copies and Adam.
 
-Tensors are torch CUDA float32, dense NCHW, used in place through their data pointers on torch's
-current stream (PyTorch is the container, as in the self-play path).
+There is no autograd here and no PyTorch arithmetic: alphapig_amd/train.py calls these functions in the order of the
+reference's graph (policy_value_net_mxnet.py:41-102, :173-212) and then in reverse.  Tensors are torch CUDA float32
+tensors used as device buffers (allocation + data pointers) on torch's current stream; without the HIP library every
+function raises.
 """
 import ctypes as C
 
@@ -13,6 +15,8 @@ from . import _native
 from ._native import ApzConfig
 
 _ENGINES = {}
+
+DENSE, ROWS16 = 0, 1       # APZ_LAYOUT_*: dense NCHW / the trunk's padded rows [n][C][15][16] (pad column zero)
 
 
 def _engine(h, w, device_index):
@@ -27,29 +31,9 @@ def _engine(h, w, device_index):
     return _ENGINES[key]
 
 
-DENSE, ROWS16 = 0, 1       # APZ_LAYOUT_*: dense NCHW / the trunk's padded rows [n][C][15][16] (pad column zero)
-
-
-def supported(x, weight, layout=DENSE):
-    co, ci, kh, kw = weight.shape
+def _torch():
     import torch
-    ok = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and kh == 3 and kw == 3
-    if layout == ROWS16:
-        return ok and (co, ci) == (128, 128) and tuple(x.shape[2:]) == (15, 16)
-    return ok and co in (64, 128, 256) and tuple(x.shape[2:]) in ((15, 15), (8, 8))
-
-
-def _wino(x, weight, layout=DENSE):
-    """The trunk shape (128 -> 128 at 15x15) runs on the fused Winograd pair kernel of the self-play path once
-    the batch fills the chip (one workgroup per pair of boards: >= 192 boards; measured 24.2 vs 31.0 ms per
-    training step at batch 512, 12.3 vs 11.8 ms at batch 128).  APZ_TRAIN_CONV=direct / wino forces a path."""
-    import os
-    if layout == ROWS16:
-        return True             # the padded-row layout IS the Winograd kernel's (no copies): always
-    if tuple(weight.shape) != (128, 128, 3, 3) or tuple(x.shape[2:]) != (15, 15):
-        return False
-    mode = os.environ.get("APZ_TRAIN_CONV", "auto")
-    return mode == "wino" or (mode != "direct" and x.shape[0] >= 192)
+    return torch
 
 
 def _ck(L, rc):
@@ -57,141 +41,253 @@ def _ck(L, rc):
         raise RuntimeError("%s (code %d)" % (L.apz_last_error().decode(), rc))
 
 
-def _function():
-    import torch
-
-    class HipConv3x3(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, weight, bias, layout):
-            L = _native.hip()
-            x = x.contiguous()
-            weight = weight.contiguous()
-            n, ci, h, w = x.shape
-            co = weight.shape[0]
-            ctx.layout = layout
-            if layout == ROWS16:
-                w = 15
-            hnd = _engine(h, w, x.device.index or 0)
-            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            y = torch.empty_like(x) if layout == ROWS16 else torch.empty((n, co, h, w), dtype=torch.float32, device=x.device)
-            bptr = bias.contiguous().data_ptr() if bias is not None else None
-            if _wino(x, weight, layout):
-                upk = torch.empty(L.apz_wino_packed_size(), dtype=torch.float32, device=x.device)
-                _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), 0, upk.data_ptr(), stream))
-                _ck(L, L.apz_wino_conv(hnd, x.data_ptr(), upk.data_ptr(), bptr, y.data_ptr(), n, 0, layout, stream))
-            else:
-                wpk = torch.empty(L.apz_conv3x3_packed_size(ci, co), dtype=torch.float32, device=x.device)
-                _ck(L, L.apz_conv3x3_pack(hnd, weight.data_ptr(), ci, co, 0, wpk.data_ptr(), stream))
-                _ck(L, L.apz_conv3x3_fwd(hnd, x.data_ptr(), wpk.data_ptr(), bptr, y.data_ptr(), n, ci, co, 0, stream))
-            ctx.save_for_backward(x, weight)
-            ctx.has_bias = bias is not None
-            return y
-
-        @staticmethod
-        def backward(ctx, dy):
-            L = _native.hip()
-            x, weight = ctx.saved_tensors
-            dy = dy.contiguous()
-            n, ci, h, w = x.shape
-            co = weight.shape[0]
-            layout = ctx.layout
-            if layout == ROWS16:
-                w = 15
-            hnd = _engine(h, w, x.device.index or 0)
-            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            dx = dw = db = None
-            if ctx.needs_input_grad[0]:
-                if _wino(x, weight, layout):
-                    upk = torch.empty(L.apz_wino_packed_size(), dtype=torch.float32, device=x.device)
-                    _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), 1, upk.data_ptr(), stream))
-                    dx = torch.empty_like(x)
-                    _ck(L, L.apz_wino_conv(hnd, dy.data_ptr(), upk.data_ptr(), None, dx.data_ptr(), n, 0, layout, stream))
-                elif ci in (64, 128, 256):
-                    wpk = torch.empty(L.apz_conv3x3_packed_size(co, ci), dtype=torch.float32, device=x.device)
-                    _ck(L, L.apz_conv3x3_pack(hnd, weight.data_ptr(), ci, co, 1, wpk.data_ptr(), stream))
-                    dx = torch.empty_like(x)
-                    _ck(L, L.apz_conv3x3_fwd(hnd, dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), n, co, ci, 0, stream))
-                else:       # e.g. a 9-plane input that needs a gradient: rare, let torch do it
-                    dx = torch.nn.grad.conv2d_input(x.shape, weight, dy, padding=1)
-            if ctx.needs_input_grad[1]:
-                dw = torch.empty_like(weight)
-                import os
-                if layout == ROWS16 and n >= 64 and os.environ.get("APZ_TRAIN_WGRAD", "wino") != "direct":
-                    _ck(L, L.apz_wgrad_wino(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, stream))
-                else:
-                    _ck(L, L.apz_conv3x3_wgrad(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, ci, co, layout, stream))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = dy.sum(dim=(0, 2, 3))       # (pad columns of a padded-row gradient are zero)
-            return dx, dw, db, None
-
-    return HipConv3x3
+def _ctx(x, layout=DENSE):
+    """-> (library, engine handle for x's board size and device, stream pointer)"""
+    torch = _torch()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("HIP operators take contiguous float32 device tensors")
+    h, w = int(x.shape[2]), int(x.shape[3])
+    if layout == ROWS16:
+        if (h, w) != (15, 16):
+            raise ValueError("padded-row tensors are [n][C][15][16]")
+        w = 15
+    return _native.hip(), _engine(h, w, x.device.index or 0), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
 
 
-_FN = None
+def _ptr(t):
+    return None if t is None else t.data_ptr()
 
 
-def conv3x3(x, weight, bias=None, layout=DENSE):
-    """y = conv2d(x, weight, bias, padding=1) on the HIP kernels, differentiable.  layout ROWS16: x and y are
-    [n][128][15][16] with a zero pad column (the self-play kernels' activation layout; no copies)."""
-    global _FN
-    if _FN is None:
-        _FN = _function()
-    return _FN.apply(x, weight, bias, layout)
+def _empty(shape, like):
+    return _torch().empty(shape, dtype=_torch().float32, device=like.device)
 
 
-def _bn_function():
-    import torch
-
-    class HipBnAct(torch.autograd.Function):
-        """Training-mode BatchNorm (+ residual) (+ ReLU) on apz_bn_fwd / apz_bn_bwd."""
-
-        @staticmethod
-        def forward(ctx, x, gamma, beta, resid, run_mean, run_var, relu, layout, momentum, eps):
-            L = _native.hip()
-            x = x.contiguous()
-            n, c, h, w = x.shape
-            hnd = _engine(h, 15 if layout == ROWS16 else w, x.device.index or 0)
-            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            y = torch.empty_like(x)
-            mean = torch.empty(c, dtype=torch.float32, device=x.device)
-            invstd = torch.empty(c, dtype=torch.float32, device=x.device)
-            rptr = resid.contiguous().data_ptr() if resid is not None else None
-            _ck(L, L.apz_bn_fwd(hnd, x.data_ptr(), rptr, gamma.data_ptr() if gamma is not None else None, beta.data_ptr(),
-                                run_mean.data_ptr(), run_var.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                n, c, layout, int(relu), momentum, eps, stream))
-            ctx.save_for_backward(x, y, gamma if gamma is not None else beta, mean, invstd)
-            ctx.cfg = (gamma is not None, resid is not None, bool(relu), layout)
-            ctx.mark_non_differentiable(run_mean, run_var)
-            return y
-
-        @staticmethod
-        def backward(ctx, dy):
-            L = _native.hip()
-            x, y, gamma, mean, invstd = ctx.saved_tensors
-            has_gamma, has_res, relu, layout = ctx.cfg
-            dy = dy.contiguous()
-            n, c, h, w = x.shape
-            hnd = _engine(h, 15 if layout == ROWS16 else w, x.device.index or 0)
-            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            dx = torch.empty_like(x)
-            dres = torch.empty_like(x) if has_res else None
-            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-            _ck(L, L.apz_bn_bwd(hnd, dy.data_ptr(), x.data_ptr(), y.data_ptr(), gamma.data_ptr() if has_gamma else None,
-                                mean.data_ptr(), invstd.data_ptr(), dx.data_ptr(), dres.data_ptr() if has_res else None,
-                                dgamma.data_ptr(), dbeta.data_ptr(), n, c, layout, int(relu), stream))
-            return dx, (dgamma if has_gamma else None), dbeta, dres, None, None, None, None, None, None
-
-    return HipBnAct
+def is_trunk_shape(weight, x, layout):
+    """128 -> 128 channels on 15x15 boards: the shape of the self-play path's fused Winograd kernel."""
+    board = (15, 16) if layout == ROWS16 else (15, 15)
+    return tuple(weight.shape) == (128, 128, 3, 3) and tuple(x.shape[2:]) == board
 
 
-_BN = None
+# ---- 3x3 convolution ------------------------------------------------------------------------------------------------
+def _conv3x3_run(x, weight, bias, layout, flip, resid, relu):
+    """conv(x, W) (flip: the data-gradient convolution with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]) + bias + resid."""
+    L, hnd, stream = _ctx(x, layout)
+    co, ci = int(weight.shape[0]), int(weight.shape[1])
+    cin_p, cout_p = (co, ci) if flip else (ci, co)
+    n = int(x.shape[0])
+    if int(x.shape[1]) != cin_p:
+        raise ValueError("channel mismatch")
+    y = _empty((n, cout_p) + tuple(x.shape[2:]), x)
+    # the Winograd kernel works on board pairs x channel halves: from 192 boards on it fills the chip and beats the
+    # direct kernel (measured round 1: 24.2 vs 31.0 ms per training step at batch 512, 12.3 vs 11.8 ms at 128);
+    # padded-row tensors are its native layout and always take it
+    if is_trunk_shape(weight, x, layout) and (layout == ROWS16 or n >= 192):
+        upk = _empty((L.apz_wino_packed_size(),), x)
+        _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), int(flip), upk.data_ptr(), stream))
+        if resid is not None and layout != ROWS16:
+            _ck(L, L.apz_wino_conv_add(hnd, x.data_ptr(), upk.data_ptr(), _ptr(bias), None, y.data_ptr(), n, 0, layout, stream))
+            add_(y, resid)
+            if relu:
+                raise ValueError("relu after a dense residual is not provided")
+        else:
+            _ck(L, L.apz_wino_conv_add(hnd, x.data_ptr(), upk.data_ptr(), _ptr(bias), _ptr(resid), y.data_ptr(), n, int(relu),
+                                       layout, stream))
+        return y
+    if layout != DENSE:
+        raise ValueError("padded-row layout: the 128 -> 128 trunk shape only")
+    wpk = _empty((L.apz_conv3x3_packed_size(cin_p, cout_p),), x)
+    _ck(L, L.apz_conv3x3_pack(hnd, weight.data_ptr(), ci, co, int(flip), wpk.data_ptr(), stream))
+    _ck(L, L.apz_conv3x3_fwd(hnd, x.data_ptr(), wpk.data_ptr(), _ptr(bias), y.data_ptr(), n, cin_p, cout_p,
+                             int(relu and resid is None), stream))
+    if resid is not None:
+        if relu:
+            raise ValueError("relu after a dense residual is not provided")
+        add_(y, resid)
+    return y
 
 
-def bn_act(x, gamma, beta, run_mean, run_var, resid=None, relu=True, layout=DENSE, momentum=0.1, eps=1e-3):
-    """act(batch_norm(x) (+ resid)) in training mode on the HIP kernels, differentiable; gamma None = fixed at 1.
-    run_mean / run_var are updated in place (momentum = weight of the new batch value, as torch)."""
-    global _BN
-    if _BN is None:
-        _BN = _bn_function()
-    return _BN.apply(x, gamma, beta, resid, run_mean, run_var, relu, layout, momentum, eps)
+def conv3x3_fwd(x, weight, bias=None, layout=DENSE, relu=False):
+    """y = conv2d(x, weight, bias, padding=1).  Dense: boards 15x15 or 8x8, C_out in {64, 128, 256}."""
+    return _conv3x3_run(x, weight, bias, layout, False, None, relu)
+
+
+def conv3x3_dgrad(dy, weight, layout=DENSE, add=None):
+    """dx = conv2d_input(dy, weight) (+ add: another gradient of the same tensor, e.g. the skip connection's).
+    Needs C_in in {64, 128, 256} (the first layer's input gradient is never wanted)."""
+    return _conv3x3_run(dy, weight, None, layout, True, add, False)
+
+
+def conv3x3_wgrad(x, dy, layout=DENSE):
+    """dw [C_out][C_in][3][3] = sum over boards of x (*) dy."""
+    L, hnd, stream = _ctx(x, layout)
+    n, ci, co = int(x.shape[0]), int(x.shape[1]), int(dy.shape[1])
+    dw = _empty((co, ci, 3, 3), x)
+    # through the Winograd domain (3.6x fewer MFMAs) once the batch covers its per-slice partial sums
+    if layout == ROWS16 and (ci, co) == (128, 128) and n >= 64:
+        _ck(L, L.apz_wgrad_wino(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, stream))
+    else:
+        _ck(L, L.apz_conv3x3_wgrad(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, ci, co, layout, stream))
+    return dw
+
+
+def bias_grad(dy, layout=DENSE):
+    """db[c] = sum over boards and cells of dy (pad cells of a padded-row gradient are zero)."""
+    L, hnd, stream = _ctx(dy, layout)
+    db = _empty((int(dy.shape[1]),), dy)
+    _ck(L, L.apz_bias_grad(hnd, dy.data_ptr(), db.data_ptr(), int(dy.shape[0]), int(dy.shape[1]), layout, stream))
+    return db
+
+
+def add_(y, x):
+    """y += x"""
+    L, hnd, stream = _ctx(y, DENSE if y.shape[3] != 16 else ROWS16)
+    if y.shape != x.shape:
+        raise ValueError("shape mismatch")
+    _ck(L, L.apz_add(hnd, y.data_ptr(), x.data_ptr(), y.numel(), stream))
+    return y
+
+
+# ---- BatchNorm ------------------------------------------------------------------------------------------------------
+def bn_fwd(x, gamma, beta, run_mean, run_var, resid=None, relu=True, layout=DENSE, momentum=0.1, eps=1e-3):
+    """y = act(batch_norm(x) (+ resid)) with batch statistics; gamma None = fixed at 1 (the reference's fix_gamma layers).
+    run_mean / run_var are updated in place (momentum = weight of the new batch value).  -> (y, mean, invstd)"""
+    L, hnd, stream = _ctx(x, layout)
+    n, c = int(x.shape[0]), int(x.shape[1])
+    y = _empty(tuple(x.shape), x)
+    mean, invstd = _empty((c,), x), _empty((c,), x)
+    _ck(L, L.apz_bn_fwd(hnd, x.data_ptr(), _ptr(resid), _ptr(gamma), beta.data_ptr(), _ptr(run_mean), _ptr(run_var),
+                        y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), n, c, layout, int(relu), momentum, eps, stream))
+    return y, mean, invstd
+
+
+def bn_bwd(dy, x, y, gamma, mean, invstd, relu=True, want_dres=False, layout=DENSE):
+    """-> (dx, dres or None, dgamma, dbeta); y is the forward output (the ReLU mask)."""
+    L, hnd, stream = _ctx(x, layout)
+    n, c = int(x.shape[0]), int(x.shape[1])
+    dx = _empty(tuple(x.shape), x)
+    dres = _empty(tuple(x.shape), x) if want_dres else None
+    dgamma, dbeta = _empty((c,), x), _empty((c,), x)
+    _ck(L, L.apz_bn_bwd(hnd, dy.data_ptr(), x.data_ptr(), y.data_ptr(), _ptr(gamma), mean.data_ptr(), invstd.data_ptr(),
+                        dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n, c, layout, int(relu), stream))
+    return dx, dres, dgamma, dbeta
+
+
+# ---- heads ----------------------------------------------------------------------------------------------------------
+def conv1x1_fwd(x, weight, bias=None, layout=DENSE):
+    """y [n][CO][H][W] (dense) = W x + b, CO <= 8."""
+    L, hnd, stream = _ctx(x, layout)
+    n, c, co = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+    h, w = int(x.shape[2]), (15 if layout == ROWS16 else int(x.shape[3]))
+    y = _empty((n, co, h, w), x)
+    _ck(L, L.apz_conv1x1_fwd(hnd, x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), n, c, co, layout, stream))
+    return y
+
+
+def conv1x1_bwd(x, weight, dy, layout=DENSE, dx=None):
+    """-> (dx, dw, db).  dx given: the gradient is ADDED to it (the second head); else a new tensor in x's layout."""
+    L, hnd, stream = _ctx(x, layout)
+    n, c, co = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+    acc = dx is not None
+    if dx is None:
+        dx = _empty(tuple(x.shape), x)
+    dw, db = _empty(tuple(weight.shape), x), _empty((co,), x)
+    _ck(L, L.apz_conv1x1_bwd(hnd, x.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                             n, c, co, layout, int(acc), stream))
+    return dx, dw, db
+
+
+def _any_engine(device_index):
+    """Operators that do not depend on the board (FullyConnected, Dropout, Adam) run on whichever engine this device
+    already has (the net's own board size), else on a 15x15 one."""
+    for (h, w, d), hnd in _ENGINES.items():
+        if d == device_index:
+            return hnd
+    return _engine(15, 15, device_index)
+
+
+def _ctx2(x):
+    torch = _torch()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("HIP operators take contiguous float32 device tensors")
+    return _native.hip(), _any_engine(x.device.index or 0), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+
+
+def fc_fwd(x, weight, bias=None):
+    """y [n][N] = x [n][K] W[N][K]^T + b"""
+    L, hnd, stream = _ctx2(x)
+    n, k, nn = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+    y = _empty((n, nn), x)
+    _ck(L, L.apz_fc_fwd(hnd, x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), n, k, nn, stream))
+    return y
+
+
+def fc_bwd(x, weight, dy):
+    """-> (dx, dw, db)"""
+    L, hnd, stream = _ctx2(x)
+    n, k, nn = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+    dx, dw, db = _empty((n, k), x), _empty((nn, k), x), _empty((nn,), x)
+    _ck(L, L.apz_fc_bwd(hnd, x.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                        n, k, nn, stream))
+    return dx, dw, db
+
+
+def dropout(x, keep, seed, step):
+    """y = x * mask / keep, mask = [hash(seed, step, element) < keep]; the same call on dy is the backward pass."""
+    L, hnd, stream = _ctx2(x)
+    y = _empty(tuple(x.shape), x)
+    _ck(L, L.apz_dropout(hnd, x.data_ptr(), y.data_ptr(), x.numel(), keep, seed, step, stream))
+    return y
+
+
+def pv_loss(logits, vlogit, pi=None, z=None, grads=True, outputs=False):
+    """The reference's loss head (policy_value_net_mxnet.py:180-193) on [n][H*W] logits and [n] value logits.
+    -> dict with loss3 = (value loss, policy loss, entropy) [device, 3 floats], dlogits, dvlogit (grads),
+    probs, values (outputs)."""
+    L, _, stream = _ctx2(logits)
+    n, hw = int(logits.shape[0]), int(logits.shape[1])
+    side = int(round(hw ** 0.5))
+    hnd = _engine(side, side, logits.device.index or 0)
+    out = {}
+    if pi is not None:
+        out["loss3"] = _empty((3,), logits)
+        if grads:
+            out["dlogits"], out["dvlogit"] = _empty((n, hw), logits), _empty((n,), logits)
+    if outputs:
+        out["probs"], out["values"] = _empty((n, hw), logits), _empty((n,), logits)
+    _ck(L, L.apz_pv_loss(hnd, logits.data_ptr(), vlogit.data_ptr(), _ptr(pi), _ptr(z), n, _ptr(out.get("loss3")),
+                         _ptr(out.get("dlogits")), _ptr(out.get("dvlogit")), _ptr(out.get("probs")), _ptr(out.get("values")),
+                         stream))
+    return out
+
+
+# ---- layout ---------------------------------------------------------------------------------------------------------
+def to_rows16(x):
+    """dense [n][C][15][15] -> padded rows [n][C][15][16] (pad column zero)"""
+    L, hnd, stream = _ctx(x, DENSE)
+    y = _empty((int(x.shape[0]), int(x.shape[1]), 15, 16), x)
+    _ck(L, L.apz_layout_convert(hnd, x.data_ptr(), y.data_ptr(), int(x.shape[0]) * int(x.shape[1]), 1, stream))
+    return y
+
+
+def from_rows16(x):
+    L, hnd, stream = _ctx(x, ROWS16)
+    y = _empty((int(x.shape[0]), int(x.shape[1]), 15, 15), x)
+    _ck(L, L.apz_layout_convert(hnd, x.data_ptr(), y.data_ptr(), int(x.shape[0]) * int(x.shape[1]), 0, stream))
+    return y
+
+
+# ---- Adam -----------------------------------------------------------------------------------------------------------
+def adam_step(entries, lr_t, b1, b2, eps, rescale, device):
+    """One launch over all tensors.  entries: [(w, grad, m, v, wd)] of float32 device tensors (apz_adam_step)."""
+    import numpy as np
+    torch = _torch()
+    tab = np.zeros(len(entries), dtype=[("w", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"), ("wd", "f4"),
+                                        ("pad", "i4")])
+    for i, (w, g, m, v, wd) in enumerate(entries):
+        if g.shape != w.shape or not g.is_contiguous():
+            raise ValueError("gradient %d: shape / layout mismatch" % i)
+        tab[i] = (w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), wd, 0)
+    L = _native.hip()
+    hnd = _any_engine(device.index or 0)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _ck(L, L.apz_adam_step(hnd, tab.ctypes.data_as(C.c_void_p), len(tab), lr_t, b1, b2, eps, rescale, stream))

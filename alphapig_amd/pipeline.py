@@ -100,12 +100,13 @@ class TrainPipeline(object):
         """train_mxnet.py:194-240."""
         mini = self._rng.sample(list(self.data_buffer), self.batch_size)
         net = self.policy_value_net
-        from .train import TorchTrainer
+        from .train import HipTrainer
         if getattr(net, "_trainer", None) is None:
-            net._trainer = TorchTrainer(net.params(), net.net_kind, net._n_blocks, batch_size=self.batch_size)
+            net._trainer = HipTrainer(net.params(), net.net_kind, net._n_blocks, batch_size=self.batch_size,
+                                      device_index=net._device)
+        # the self-play evaluator itself supplies the old / new predictions of the KL monitor (re-folded per epoch)
         loss, entropy, kl, self.lr_multiplier = policy_update(net._trainer, mini, self.learn_rate, self.lr_multiplier,
-                                                              self.epochs, self.kl_targ)
-        net.set_params(net._trainer.get_params(), _keep_trainer=True)
+                                                              self.epochs, self.kl_targ, evaluator=_KeepTrainer(net))
         _logger.info("kl:%.4f lr_multiplier:%.3f loss:%.4f entropy:%.4f", kl, self.lr_multiplier, loss, entropy)
         return loss, entropy, kl
 
@@ -145,6 +146,20 @@ class TrainPipeline(object):
     def close(self):
         self.engine.close()
         self.policy_value_net.close()
+
+
+class _KeepTrainer(object):
+    """policy_update's evaluator: the net's own HIP inference engine, re-folded from the trainer's weights without
+    dropping the trainer's optimiser state."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def policy_value(self, states):
+        return self.net.policy_value(states)
+
+    def set_params(self, prm):
+        self.net.set_params(prm, _keep_trainer=True)
 
 
 class _NoPlayer(object):

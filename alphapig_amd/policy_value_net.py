@@ -33,6 +33,7 @@ class PolicyValueNet(object):
         self.channelnum = int(c_in)
         self._n_blocks, self._n_filter = int(n_blocks), int(n_filter)
         self.net_kind = net_kind
+        self._device = int(device)
         self.hw = self.board_width * self.board_height
         self.code_stride = (self.hw + 1 + 15) // 16 * 16
         kind = {"resnet": 0, "simple": 1}[net_kind]
@@ -233,11 +234,12 @@ class PolicyValueNet(object):
     def train_step(self, state_batch, mcts_probs, winner_batch, learning_rate):
         """One optimiser step (policy_value_net_mxnet.py:282-299) -> (loss, entropy), then the new
         weights are re-folded into the HIP evaluator like the reference re-syncs its predict
-        modules (:295-297).  INTERIM backward pass: PyTorch-ROCm autograd (alphapig_amd/train.py,
-        SURVEY.md 8f rank 1); the self-play hot path never touches it."""
-        from .train import TorchTrainer
+        modules (:295-297).  Forward, backward and Adam run on the HIP kernels (alphapig_amd/train.py,
+        SURVEY.md 8f rank 1); the self-play hot path never touches them."""
+        from .train import HipTrainer
         if getattr(self, "_trainer", None) is None:
-            self._trainer = TorchTrainer(self._params, self.net_kind, self._n_blocks, batch_size=self.batchsize)
+            self._trainer = HipTrainer(self._params, self.net_kind, self._n_blocks, batch_size=self.batchsize,
+                                       device_index=self._device)
         loss, entropy = self._trainer.train_step(state_batch, mcts_probs, winner_batch, learning_rate)
         self.set_params(self._trainer.get_params(), _keep_trainer=True)
         return np.array([loss], dtype=np.float32), np.array([entropy], dtype=np.float32)

@@ -1,23 +1,28 @@
-"""Training step -- INTERIM implementation of the first "next" row.
+"""Training step on the HIP kernels: the consumer of the self-play path's tuples.
 
-The self-play hot path (this repository's scope) is hand-written HIP; the training step that
-consumes its tuples is, for now, PyTorch-ROCm autograd over the same MXNet-named parameter dict
-(SURVEY.md 8f explicitly allows that interim).  What IS restated by hand is everything the
-reference defines around the backward pass (reference policy_value_net_mxnet.py:173-212,
-:282-299 and train_mxnet.py:194-240):
+Everything the reference defines around the optimiser step (policy_value_net_mxnet.py:173-212, :282-299 and
+train_mxnet.py:194-240) restated as an explicit forward pass, an explicit backward pass over the saved activations
+and one Adam launch -- each operator a hand-written HIP kernel behind include/alphapig_hip.h (alphapig_amd/hipconv.py
+holds the one-line wrappers).  No autograd and no PyTorch arithmetic: torch tensors are device buffers here, as in
+the self-play path.  The module needs the HIP library and a GPU; without them construction raises.
 
+  graph     training-mode BatchNorm (batch statistics, eps 1e-3, momentum 0.9, gamma frozen at 1 where the
+            reference leaves fix_gamma at MXNet's default), Dropout(0.5) on both flattened head inputs (the training
+            graph shares create_backbone_resnet), softmax / tanh heads
   loss      mean((z - v)^2) + mean(-sum(pi * log p, axis=1)); entropy monitor mean(sum(-p log p))
-  graph     training-mode BatchNorm (batch statistics, eps 1e-3, momentum 0.9, gamma frozen at 1
-            where the reference leaves fix_gamma at MXNet's default), Dropout(0.5) on both
-            flattened head inputs (the training graph shares create_backbone_resnet)
-  update    MXNet Adam as Module.init_optimizer configures it: g = grad / batch_size + wd * w
-            (rescale_grad = 1/batch_size on top of the mean loss; wd = 1e-4 on *_weight and
-            *_gamma only), m/v moments, lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), eps 1e-8
-  policy_update   epochs x train_step with the KL-adaptive learning-rate multiplier and the
-            4 * kl_targ early stop
+  update    MXNet Adam as Module.init_optimizer configures it: g = grad / batch_size + wd * w (rescale_grad =
+            1/batch_size on top of the mean loss; wd = 1e-4 on *_weight and *_gamma only), m/v moments,
+            lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), eps 1e-8
+  policy_update   epochs x train_step with the KL-adaptive learning-rate multiplier and the 4 * kl_targ early stop
 
-PARITY UNPINNED like the forward (MXNet absent, no recorded training runs); checked against
-oracle/train_ref.py (NumPy float64 loss + finite differences, NumPy Adam) in tests/test_train.py.
+The 10-block / 128-filter / 15x15 network keeps its trunk activations in the self-play kernels' padded-row layout
+[n][128][15][16] from the stem's BatchNorm to the heads (forward and data gradient on the fused Winograd kernel of
+the self-play path, weight gradient through the Winograd domain); other shapes (the 8x8 simple net, other filter
+counts) run dense on the direct MFMA kernel.
+
+PARITY UNPINNED like the forward's numbers (MXNet absent, no recorded training runs).  Checked on the GPU against
+tests/torch_trainer.py (the same graph in PyTorch float64 / float32 autograd), which tests/test_train.py in turn
+checks against oracle/train_ref.py (NumPy float64 loss + finite differences, NumPy Adam).
 """
 import collections
 
@@ -25,41 +30,28 @@ import numpy as np
 
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.9
+SIMPLE_CONVS = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv_final")
 
 
-def _torch():
-    import torch
-    return torch
-
-
-class TorchTrainer(object):
-    def __init__(self, params, net_kind="resnet", n_blocks=10, batch_size=512, wd=1e-4, device=None,
-                 dtype=None, dropout=0.5, seed=0, conv_backend=None, trunk_backend=None):
-        torch = _torch()
-        self.torch = torch
+class HipTrainer(object):
+    def __init__(self, params, net_kind="resnet", n_blocks=10, batch_size=512, wd=1e-4, device_index=0, dropout=0.5,
+                 seed=0):
+        import torch
+        from . import _native, hipconv
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipTrainer needs a GPU: the training step has no CPU path")
+        _native.hip()                          # raises when libalphapig_hip.so is missing
+        self.torch, self.ops = torch, hipconv
         self.kind, self.n_blocks = net_kind, n_blocks
-        self.batch_size, self.wd, self.dropout = batch_size, wd, dropout
-        # "hip": 3x3 convolutions (forward, dgrad, wgrad), the trunk's BatchNorm and Adam on this repository's
-        # kernels (hipconv.py) -- the default on a GPU; "torch": everything in PyTorch (the CPU path, and the
-        # reference graph the HIP path is tested against)
-        self.conv_backend = conv_backend
-        # "hip16": the residual trunk end to end on HIP kernels in the self-play path's padded-row layout --
-        # Winograd pair kernel for forward / data gradient (no layout copies), weight-gradient kernel on the same
-        # layout, BatchNorm (+ residual) + ReLU forward and backward (hipconv.bn_act).  Default: on whenever the
-        # 3x3 convolutions are on HIP and the net is the 15x15 / 128-filter one; trunk_backend="torch" turns it off.
-        self.trunk_backend = trunk_backend
-        if device is None:
-            device = "cuda" if torch.cuda.is_available() else "cpu"
-        self.device = torch.device(device)
-        self.dtype = dtype or torch.float32
-        if self.conv_backend is None:
-            self.conv_backend = "hip" if (self.device.type == "cuda" and self.dtype == torch.float32) else "torch"
-        self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(seed)
+        self.batch_size, self.wd, self.dropout, self.seed = batch_size, wd, dropout, seed
+        self.device = torch.device("cuda", device_index)
         self.p = collections.OrderedDict()
         for k, v in params.items():
-            t = torch.tensor(np.asarray(v), dtype=self.dtype, device=self.device)
-            self.p[k] = t
+            self.p[k] = torch.tensor(np.ascontiguousarray(v, dtype=np.float32), device=self.device)
+        first = next(iter(self.p.values()))
+        self.c_in = int(first.shape[1])
+        self.hw = int(self.p["fc_3_1_1_bias"].shape[0])
+        self.side = int(round(self.hw ** 0.5))
         self.stat_names = [k for k in self.p if k.endswith(("_mean", "_var", "_moving_mean", "_moving_var"))]
         # gammas of the fix_gamma BatchNorm layers (every conv_act layer: res_conv1, the two 1x1 heads, and all of the
         # simple net; policy_value_loss.json nodes 9 / 208 / 226 carry no fix_gamma=False) never enter the graph.
@@ -69,161 +61,188 @@ class TorchTrainer(object):
         for k in self.fixed_gamma_names:
             self.p[k].fill_(1.0)
         self.train_names = [k for k in self.p if k not in self.stat_names and k not in self.fixed_gamma_names]
-        for k in self.train_names:
-            self.p[k].requires_grad_(True)
         self.m = {k: torch.zeros_like(self.p[k]) for k in self.train_names}
         self.v = {k: torch.zeros_like(self.p[k]) for k in self.train_names}
         self.t = 0
+        self.grad = {}
+        # the self-play kernels' padded-row layout for the trunk when the net has their shape
+        self.rows16 = (net_kind == "resnet" and n_blocks > 0 and self.side == 15 and
+                       tuple(self.p["convA1_weight"].shape) == (128, 128, 3, 3))
+        self._eval = None
+        self._eval_t = -1
+        self.tape = None
 
-    # ---- graph ------------------------------------------------------------------------------
-    def _bn(self, x, name, fix_gamma, mean_n, var_n, train):
-        F = self.torch.nn.functional
-        gamma = None if fix_gamma else self.p[name + "_gamma"]
-        if gamma is None:
-            gamma = self.torch.ones_like(self.p[name + "_beta"])
-        rm, rv = self.p[name + mean_n], self.p[name + var_n]
-        return F.batch_norm(x, rm, rv, gamma, self.p[name + "_beta"], training=train,
-                            momentum=1.0 - BN_MOMENTUM, eps=BN_EPS)
-
-    def _conv(self, x, w, b, k):
-        if k == 3 and self.conv_backend == "hip":
-            from . import hipconv
-            if hipconv.supported(x, w):
-                return hipconv.conv3x3(x, w, b)
-        return self.torch.nn.functional.conv2d(x, w, b, padding=k // 2)
-
-    def _conv_act(self, x, name, k, train):
-        F = self.torch.nn.functional
-        y = self._conv(x, self.p[name + "_weight"], self.p[name + "_bias"], k)
-        return F.relu(self._bn(y, name, True, "_mean", "_var", train))
-
-    def _use_hip16(self, x, train):
-        if self.trunk_backend == "torch" or self.conv_backend != "hip" or not train or self.kind != "resnet":
-            return False
-        return (x.is_cuda and tuple(x.shape[1:]) == (128, 15, 15) and x.dtype == self.torch.float32 and
-                (self.trunk_backend == "hip16" or x.shape[0] >= 192))
-
-    def _trunk_hip16(self, x):
-        """The residual blocks on padded-row tensors [n][128][15][16] (training mode)."""
-        from . import hipconv
-        F = self.torch.nn.functional
-        x = F.pad(x, (0, 1))                     # dense -> padded rows (pad column zero)
-        p = self.p
-        for i in range(1, self.n_blocks + 1):
-            skip = x
-            y = hipconv.conv3x3(x, p["convA%d_weight" % i], p["convA%d_bias" % i], hipconv.ROWS16)
-            y = hipconv.bn_act(y, p["bnA%d_gamma" % i], p["bnA%d_beta" % i], p["bnA%d_moving_mean" % i],
-                               p["bnA%d_moving_var" % i], None, True, hipconv.ROWS16, 1.0 - BN_MOMENTUM, BN_EPS)
-            y = hipconv.conv3x3(y, p["convB%d_weight" % i], p["convB%d_bias" % i], hipconv.ROWS16)
-            x = hipconv.bn_act(y, p["bnB%d_gamma" % i], p["bnB%d_beta" % i], p["bnB%d_moving_mean" % i],
-                               p["bnB%d_moving_var" % i], skip, True, hipconv.ROWS16, 1.0 - BN_MOMENTUM, BN_EPS)
-        return x[..., :15].contiguous()
-
-    def forward(self, states, train=True):
-        torch, F = self.torch, self.torch.nn.functional
-        x = states
-        if self.kind == "resnet":
-            x = self._conv_act(x, "res_conv1", 3, train)
-            hip16 = self._use_hip16(x, train)
-            if hip16:
-                x = self._trunk_hip16(x)
-            for i in range(1, 0 if hip16 else self.n_blocks + 1):
-                skip = x
-                y = self._conv(x, self.p["convA%d_weight" % i], self.p["convA%d_bias" % i], 3)
-                y = F.relu(self._bn(y, "bnA%d" % i, False, "_moving_mean", "_moving_var", train))
-                y = self._conv(y, self.p["convB%d_weight" % i], self.p["convB%d_bias" % i], 3)
-                y = self._bn(y, "bnB%d" % i, False, "_moving_mean", "_moving_var", train)
-                x = F.relu(y + skip)
+    # ---- forward: every activation the backward pass reads goes on the tape -----------------------------------------
+    def _conv_act_fwd(self, x, name, layout):
+        """conv_act of the reference (policy_value_net_mxnet.py:28-39): Convolution -> BatchNorm(fix_gamma) -> relu"""
+        o, p = self.ops, self.p
+        w = p[name + "_weight"]
+        if w.shape[2] == 1:
+            y = o.conv1x1_fwd(x, w, p[name + "_bias"], layout)
+            blay = o.DENSE
         else:
-            for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv_final"):
-                x = self._conv_act(x, name, 3, train)
-        n = x.shape[0]
-        pol = self._conv_act(x, "conv3_1_1", 1, train).reshape(n, -1)
-        val = self._conv_act(x, "conv3_2_1", 1, train).reshape(n, -1)
-        if train and self.dropout > 0:
+            y = o.conv3x3_fwd(x, w, p[name + "_bias"], layout)
+            blay = layout
+        a, mean, invstd = o.bn_fwd(y, None, p[name + "_beta"], p[name + "_mean"], p[name + "_var"], None, True, blay,
+                                   1.0 - BN_MOMENTUM, BN_EPS)
+        return a, (name, x, y, a, mean, invstd, layout)
+
+    def _conv_act_bwd(self, da, rec, need_dx, dx_acc=None):
+        o, p, g = self.ops, self.p, self.grad
+        name, x, y, a, mean, invstd, layout = rec
+        w = p[name + "_weight"]
+        one = w.shape[2] == 1
+        dy, _, _, g[name + "_beta"] = o.bn_bwd(da, y, a, None, mean, invstd, True, False, o.DENSE if one else layout)
+        if one:
+            dx, g[name + "_weight"], g[name + "_bias"] = o.conv1x1_bwd(x, w, dy, layout, dx_acc)
+            return dx
+        g[name + "_weight"] = o.conv3x3_wgrad(x, dy, layout)
+        g[name + "_bias"] = o.bias_grad(dy, layout)
+        return o.conv3x3_dgrad(dy, w, layout) if need_dx else None
+
+    def _forward(self, states, step):
+        o, p = self.ops, self.p
+        tape = {"blocks": [], "stack": []}
+        if self.kind == "resnet":
+            x, rec = self._conv_act_fwd(states, "res_conv1", o.DENSE)
+            tape["stem"] = rec
+            lay = o.ROWS16 if self.rows16 else o.DENSE
+            if self.rows16:
+                x = o.to_rows16(x)
+            for i in range(1, self.n_blocks + 1):
+                A, B = "A%d" % i, "B%d" % i
+                ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay)
+                ha, ma, ia = o.bn_fwd(ya, p["bn" + A + "_gamma"], p["bn" + A + "_beta"], p["bn" + A + "_moving_mean"],
+                                      p["bn" + A + "_moving_var"], None, True, lay, 1.0 - BN_MOMENTUM, BN_EPS)
+                yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay)
+                out, mb, ib = o.bn_fwd(yb, p["bn" + B + "_gamma"], p["bn" + B + "_beta"], p["bn" + B + "_moving_mean"],
+                                       p["bn" + B + "_moving_var"], x, True, lay, 1.0 - BN_MOMENTUM, BN_EPS)
+                tape["blocks"].append((x, ya, ha, ma, ia, yb, out, mb, ib))
+                x = out
+        else:
+            lay = o.DENSE
+            x = states
+            for name in SIMPLE_CONVS:
+                x, rec = self._conv_act_fwd(x, name, lay)
+                tape["stack"].append(rec)
+        tape["layout"] = lay
+        n = int(x.shape[0])
+        pol, tape["pol"] = self._conv_act_fwd(x, "conv3_1_1", lay)
+        val, tape["val"] = self._conv_act_fwd(x, "conv3_2_1", lay)
+        pol, val = pol.view(n, -1), val.view(n, -1)
+        if self.dropout > 0:
             keep = 1.0 - self.dropout
-            pol = pol * (torch.rand(pol.shape, generator=self.gen, device=self.device, dtype=self.dtype) < keep) / keep
-            val = val * (torch.rand(val.shape, generator=self.gen, device=self.device, dtype=self.dtype) < keep) / keep
-        logits = pol @ self.p["fc_3_1_1_weight"].t() + self.p["fc_3_1_1_bias"]
-        logp = F.log_softmax(logits, dim=1)
-        v = torch.tanh(val @ self.p["fc_3_2_1_weight"].t() + self.p["fc_3_2_1_bias"])
-        return logp, v
+            pol = o.dropout(pol, keep, self.seed, 2 * step)
+            val = o.dropout(val, keep, self.seed, 2 * step + 1)
+        tape["pol_in"], tape["val_in"] = pol, val
+        logits = o.fc_fwd(pol, p["fc_3_1_1_weight"], p["fc_3_1_1_bias"])
+        vlogit = o.fc_fwd(val, p["fc_3_2_1_weight"], p["fc_3_2_1_bias"]).view(n)
+        return logits, vlogit, tape
 
-    def loss(self, states, mcts_probs, winners, train=True):
-        logp, v = self.forward(states, train)
-        value_loss = ((winners.reshape(-1, 1) - v) ** 2).mean()
-        policy_loss = (-(logp * mcts_probs).sum(dim=1)).mean()
-        entropy = (-(logp.exp() * logp).sum(dim=1)).mean()
-        return value_loss + policy_loss, entropy
+    # ---- backward ---------------------------------------------------------------------------------------------------
+    def _backward(self, tape, dlogits, dvlogit):
+        o, p, g = self.ops, self.p, self.grad
+        n = int(dlogits.shape[0])
+        lay = tape["layout"]
+        dpol, g["fc_3_1_1_weight"], g["fc_3_1_1_bias"] = o.fc_bwd(tape["pol_in"], p["fc_3_1_1_weight"], dlogits)
+        dval, g["fc_3_2_1_weight"], g["fc_3_2_1_bias"] = o.fc_bwd(tape["val_in"], p["fc_3_2_1_weight"], dvlogit.view(n, 1))
+        if self.dropout > 0:
+            keep = 1.0 - self.dropout
+            dpol = o.dropout(dpol, keep, self.seed, 2 * tape["step"])
+            dval = o.dropout(dval, keep, self.seed, 2 * tape["step"] + 1)
+        dx = self._conv_act_bwd(dpol.view(n, 4, self.side, self.side), tape["pol"], True)
+        dx = self._conv_act_bwd(dval.view(n, 2, self.side, self.side), tape["val"], True, dx_acc=dx)
+        if self.kind == "resnet":
+            for i in range(self.n_blocks, 0, -1):
+                A, B = "A%d" % i, "B%d" % i
+                x, ya, ha, ma, ia, yb, out, mb, ib = tape["blocks"][i - 1]
+                dyb, dskip, g["bn" + B + "_gamma"], g["bn" + B + "_beta"] = o.bn_bwd(dx, yb, out, p["bn" + B + "_gamma"], mb, ib,
+                                                                                    True, True, lay)
+                g["conv" + B + "_weight"] = o.conv3x3_wgrad(ha, dyb, lay)
+                g["conv" + B + "_bias"] = o.bias_grad(dyb, lay)
+                dha = o.conv3x3_dgrad(dyb, p["conv" + B + "_weight"], lay)
+                dya, _, g["bn" + A + "_gamma"], g["bn" + A + "_beta"] = o.bn_bwd(dha, ya, ha, p["bn" + A + "_gamma"], ma, ia,
+                                                                                True, False, lay)
+                g["conv" + A + "_weight"] = o.conv3x3_wgrad(x, dya, lay)
+                g["conv" + A + "_bias"] = o.bias_grad(dya, lay)
+                dx = o.conv3x3_dgrad(dya, p["conv" + A + "_weight"], lay, add=dskip)   # trunk + skip gradients meet
+            if self.rows16:
+                dx = o.from_rows16(dx)
+            self._conv_act_bwd(dx, tape["stem"], False)
+        else:
+            for j in range(len(SIMPLE_CONVS) - 1, -1, -1):
+                dx = self._conv_act_bwd(dx, tape["stack"][j], j > 0)
 
-    # ---- one optimiser step (policy_value_net_mxnet.py:282-299) ------------------------------
+    # ---- one optimiser step (policy_value_net_mxnet.py:282-299) -----------------------------------------------------
     def _to(self, a, shape):
-        return self.torch.as_tensor(np.asarray(a), dtype=self.dtype, device=self.device).reshape(shape)
+        t = self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).reshape(shape)
+        return t.to(self.device).contiguous()
 
-    def train_step(self, state_batch, mcts_probs, winner_batch, learning_rate):
-        torch = self.torch
-        c = self.p[next(iter(self.p))].shape[1]
-        hw = self.p["fc_3_1_1_bias"].shape[0]
-        side = int(round(hw ** 0.5))
-        states = self._to(state_batch, (-1, c, side, side))
-        pis = self._to(mcts_probs, (-1, hw))
+    def loss_and_grads(self, state_batch, mcts_probs, winner_batch, keep_tape=False):
+        """Forward + backward in training mode (moving statistics are updated).  -> (loss3 device tensor =
+        (value loss, policy loss, entropy)); the gradients of the MEAN loss land in self.grad.  keep_tape: hold on to
+        the saved activations afterwards (relu_masks(); tests)."""
+        states = self._to(state_batch, (-1, self.c_in, self.side, self.side))
+        pis = self._to(mcts_probs, (-1, self.hw))
         zs = self._to(winner_batch, (-1,))
-        for k in self.train_names:
-            self.p[k].grad = None
-        loss, entropy = self.loss(states, pis, zs, train=True)
-        loss.backward()
+        self.grad = {}
+        logits, vlogit, tape = self._forward(states, self.t)
+        tape["step"] = self.t
+        out = self.ops.pv_loss(logits, vlogit, pis, zs, grads=True)
+        self._backward(tape, out["dlogits"], out["dvlogit"])
+        self.tape = tape if keep_tape else None
+        return out["loss3"]
+
+    def relu_masks(self):
+        """{layer: [n][C][H][W] bool} -- which activations of the kept forward pass were positive.  (A comparator that
+        takes its ReLU decisions from here differs from this trainer by rounding only: an activation within rounding
+        distance of zero otherwise lands on different sides in different arithmetic and moves whole gradient rows.)"""
+        cut = (lambda t: t[..., :15]) if self.rows16 else (lambda t: t)
+        tape, out = self.tape, {}
+        recs = [tape["pol"], tape["val"]] + tape["stack"] + ([tape["stem"]] if "stem" in tape else [])
+        for rec in recs:
+            out[rec[0]] = rec[3] > 0
+        for i, blk in enumerate(tape["blocks"], 1):
+            out["bnA%d" % i] = cut(blk[2]) > 0
+            out["block%d" % i] = cut(blk[6]) > 0
+        return out
+
+    def train_step(self, state_batch, mcts_probs, winner_batch, learning_rate, keep_tape=False):
+        loss3 = self.loss_and_grads(state_batch, mcts_probs, winner_batch, keep_tape)
         self.t += 1
         b1, b2, eps = 0.9, 0.999, 1e-8
         lr_t = learning_rate * (1.0 - b2 ** self.t) ** 0.5 / (1.0 - b1 ** self.t)
-        rescale = 1.0 / self.batch_size
-        if self.conv_backend == "hip" and self.device.type == "cuda" and self.dtype == torch.float32:
-            self._adam_hip(lr_t, b1, b2, eps, rescale)        # one launch over all tensors
-        else:
-            with torch.no_grad():
-                for k in self.train_names:
-                    w = self.p[k]
-                    g = w.grad if w.grad is not None else torch.zeros_like(w)
-                    wd = self.wd if k.endswith(("_weight", "_gamma")) else 0.0
-                    g = g * rescale + wd * w
-                    self.m[k].mul_(b1).add_(g, alpha=1.0 - b1)
-                    self.v[k].mul_(b2).addcmul_(g, g, value=1.0 - b2)
-                    w.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + eps))
-        return float(loss.detach().cpu()), float(entropy.detach().cpu())
-
-    def _adam_hip(self, lr_t, b1, b2, eps, rescale):
-        """The same update as the loop above through apz_adam_step: a table of (w, grad, m, v, n, wd) per tensor."""
-        import ctypes as C
-        from . import _native, hipconv
-        torch = self.torch
-        tab = np.zeros(len(self.train_names), dtype=[("w", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"),
-                                                     ("wd", "f4"), ("pad", "i4")])
-        keep = []
-        for i, k in enumerate(self.train_names):
-            w = self.p[k]
-            g = w.grad if w.grad is not None else torch.zeros_like(w)
-            g = g.contiguous()
-            keep.append(g)
-            tab[i] = (w.data_ptr(), g.data_ptr(), self.m[k].data_ptr(), self.v[k].data_ptr(), w.numel(),
-                      self.wd if k.endswith(("_weight", "_gamma")) else 0.0, 0)
-        L = _native.hip()
-        hnd = hipconv._engine(15, 15, self.device.index or 0)
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = L.apz_adam_step(hnd, tab.ctypes.data_as(C.c_void_p), len(tab), lr_t, b1, b2, eps, rescale, stream)
-        if rc < 0:
-            raise RuntimeError(L.apz_last_error().decode())
+        entries = [(self.p[k], self.grad[k], self.m[k], self.v[k], self.wd if k.endswith(("_weight", "_gamma")) else 0.0)
+                   for k in self.train_names]
+        self.ops.adam_step(entries, lr_t, b1, b2, eps, 1.0 / self.batch_size, self.device)
+        l3 = loss3.cpu().numpy()           # the step's only device -> host copy (12 bytes), and its synchronisation
+        return float(l3[0] + l3[1]), float(l3[2])
 
     def policy_value(self, state_batch):
-        """Inference-mode (moving statistics) probabilities and values, for the KL monitor."""
-        torch = self.torch
-        c = self.p[next(iter(self.p))].shape[1]
-        hw = self.p["fc_3_1_1_bias"].shape[0]
-        side = int(round(hw ** 0.5))
-        with torch.no_grad():
-            logp, v = self.forward(self._to(state_batch, (-1, c, side, side)), train=False)
-        return logp.exp().cpu().numpy(), v.cpu().numpy()
+        """Inference-mode (moving statistics) probabilities and values for the KL monitor: the self-play path's own
+        evaluator (PolicyValueNet) on the current weights."""
+        from .policy_value_net import PolicyValueNet
+        if self._eval is None:
+            nf = int(next(iter(self.p.values())).shape[0]) if self.kind == "resnet" else 128
+            self._eval = PolicyValueNet(self.side, self.side, batch_size=self.batch_size, n_blocks=self.n_blocks, n_filter=nf,
+                                        model_params=self.get_params(), net_kind=self.kind, c_in=self.c_in,
+                                        device=self.device.index or 0)
+            self._eval_t = self.t
+        elif self._eval_t != self.t:
+            self._eval.set_params(self.get_params())
+            self._eval_t = self.t
+        return self._eval.policy_value(state_batch)
 
     def get_params(self):
-        return collections.OrderedDict((k, v.detach().cpu().numpy().astype(np.float32)) for k, v in self.p.items())
+        return collections.OrderedDict((k, v.cpu().numpy()) for k, v in self.p.items())
+
+    def get_grads(self):
+        return collections.OrderedDict((k, self.grad[k].cpu().numpy()) for k in self.train_names)
+
+    def close(self):
+        if self._eval is not None:
+            self._eval.close()
+            self._eval = None
 
 
 def policy_update(trainer, mini_batch, learn_rate=1e-3, lr_multiplier=1.0, epochs=8, kl_targ=0.02, evaluator=None):

@@ -155,6 +155,10 @@ int64_t apz_wino_packed_size(void);
 int apz_wino_pack(apz_engine *e, const void *w_dev, int transpose_flip, void *upk_dev, void *stream);
 int apz_wino_conv(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev,
                   void *y_dev, int n, int relu, int layout, void *stream);
+/* ... + resid_dev (padded-row layout only; NULL: none) before the ReLU: the data gradient of a residual block's first
+ * convolution meets the skip gradient inside the kernel's epilogue (trunk15_wino3.h) */
+int apz_wino_conv_add(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev,
+                      const void *resid_dev, void *y_dev, int n, int relu, int layout, void *stream);
 /* Training-mode BatchNorm (+ residual) (+ ReLU), the reference's BatchNorm(eps = 1e-3) between the trunk's
  * convolutions (policy_value_net_mxnet.py:41-102), over n x C planes in `layout`:
  *   apz_bn_fwd  y = act((x - mean_c) * invstd_c * gamma_c + beta_c (+ resid)); batch statistics (biased
@@ -181,6 +185,40 @@ int apz_bn_bwd(apz_engine *e, const void *dy_dev, const void *x_dev, const void 
                const void *gamma_dev, const void *mean_dev, const void *invstd_dev, void *dx_dev,
                void *dres_dev, void *dgamma_dev, void *dbeta_dev, int n, int C, int layout, int relu,
                void *stream);
+
+/* ---- heads and loss of the training graph (policy_value_net_mxnet.py:85-102, :173-193), csrc/heads_train.h.
+ * All tensors float32 on the device; `layout` as above for the trunk-side tensors (x, dx); y / dy dense.
+ *   apz_conv1x1_fwd / _bwd   the 1x1 head convolutions conv3_1_1 (C -> 4) and conv3_2_1 (C -> 2): y = W x + b;
+ *                            dx (NULL: not wanted), dW [CO][C], db [CO] (NULL: not wanted); sums over the batch are
+ *                            taken in index order (no float atomics)
+ *   apz_fc_fwd / _bwd        FullyConnected: y[n][N] = x[n][K] W[N][K]^T + b; dx, dW, db (each may be NULL): one
+ *                            fp32-MFMA GEMM kernel with operand strides
+ *   apz_dropout              y = x * mask / keep, mask = [hash(seed, step, index) < keep]: the same call with dy gives
+ *                            the backward pass (the mask is regenerated, not stored)
+ *   apz_pv_loss              p = softmax(logits), v = tanh(vlogit); loss3 = (mean (z - v)^2, mean -sum pi log p,
+ *                            mean -sum p log p); dlogits = (p sum(pi) - pi) / n, dvlogit = 2 (v - z)(1 - v^2) / n;
+ *                            probs / values = p, v.  Every output pointer may be NULL.
+ *   apz_layout_convert       dense [planes][15][15] <-> padded rows [planes][15][16]
+ *   apz_bias_grad            db[c] = sum over boards and cells of dy[n][c][.] (the bias gradient of a convolution;
+ *                            pad cells of a padded-row gradient are zero), fixed summation order
+ *   apz_add                  y += x (count floats): the meeting point of the trunk and skip gradients
+ * conv1x1_bwd: dx gets zero pad cells; accumulate_dx != 0 adds to what dx already holds (second head). */
+int apz_conv1x1_fwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *bias_dev, void *y_dev, int n,
+                    int C, int CO, int layout, void *stream);
+int apz_conv1x1_bwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *dy_dev, void *dx_dev,
+                    void *dw_dev, void *db_dev, int n, int C, int CO, int layout, int accumulate_dx, void *stream);
+int apz_bias_grad(apz_engine *e, const void *dy_dev, void *db_dev, int n, int C, int layout, void *stream);
+int apz_add(apz_engine *e, void *y_dev, const void *x_dev, int64_t count, void *stream);
+int apz_fc_fwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *bias_dev, void *y_dev, int n, int K,
+               int N, void *stream);
+int apz_fc_bwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *dy_dev, void *dx_dev, void *dw_dev,
+               void *db_dev, int n, int K, int N, void *stream);
+int apz_dropout(apz_engine *e, const void *x_dev, void *y_dev, int64_t count, float keep, uint64_t seed,
+                uint64_t step, void *stream);
+int apz_pv_loss(apz_engine *e, const void *logits_dev, const void *vlogit_dev, const void *pi_dev, const void *z_dev,
+                int n, void *loss3_dev, void *dlogits_dev, void *dvlogit_dev, void *probs_dev, void *values_dev,
+                void *stream);
+int apz_layout_convert(apz_engine *e, const void *src_dev, void *dst_dev, int64_t planes, int to_rows16, void *stream);
 
 int apz_sync(apz_engine *e);
 void *apz_stream(apz_engine *e);

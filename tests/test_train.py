@@ -1,5 +1,7 @@
-"""Interim training step (PARITY UNPINNED): autograd graph vs NumPy float64 loss
-and finite differences, Adam update vs its NumPy restatement, KL-adaptive policy_update."""
+"""Training step (PARITY UNPINNED), CPU side: the PyTorch comparator of the HIP trainer
+(tests/torch_trainer.py) vs the NumPy float64 oracle -- loss, finite differences, Adam -- and the KL-adaptive
+policy_update loop of alphapig_amd/train.py driven by it.  (The HIP trainer itself against the comparator:
+tests/test_gpu_train.py.)"""
 import numpy as np
 import pytest
 
@@ -19,7 +21,7 @@ def tiny_problem(seed=0, n=6, w=8, blocks=1, filt=16):
 
 
 def test_loss_and_gradients_match_numpy_oracle():
-    from alphapig_amd.train import TorchTrainer
+    from torch_trainer import TorchTrainer
     prm, states, pis, zs = tiny_problem()
     tr = TorchTrainer(prm, "resnet", n_blocks=1, batch_size=6, device="cpu", dtype=torch.float64, dropout=0.0)
     st = torch.tensor(states, dtype=torch.float64)
@@ -39,7 +41,7 @@ def test_loss_and_gradients_match_numpy_oracle():
 
 
 def test_adam_update_rule():
-    from alphapig_amd.train import TorchTrainer
+    from torch_trainer import TorchTrainer
     prm, states, pis, zs = tiny_problem(seed=3)
     tr = TorchTrainer(prm, "resnet", n_blocks=1, batch_size=128, device="cpu", dtype=torch.float64, dropout=0.0)
     # expected: two steps of the NumPy rule driven by the trainer's own gradients
@@ -70,7 +72,8 @@ def test_adam_update_rule():
 
 
 def test_policy_update_reduces_loss_and_adapts_lr():
-    from alphapig_amd.train import TorchTrainer, policy_update
+    from alphapig_amd.train import policy_update
+    from torch_trainer import TorchTrainer
     prm, states, pis, zs = tiny_problem(seed=5, n=32)
     tr = TorchTrainer(prm, "resnet", n_blocks=1, batch_size=32, device="cpu", dropout=0.5, seed=1)
     batch = [(states[i], pis[i], zs[i]) for i in range(32)]
@@ -82,3 +85,13 @@ def test_policy_update_reduces_loss_and_adapts_lr():
         assert np.isfinite(loss) and np.isfinite(ent) and kl >= -1e-6
     assert loss < first
     assert 0.05 / 1.5 <= mult <= 20 * 1.5
+
+
+def test_product_trainer_has_no_cpu_path():
+    """alphapig_amd.train.HipTrainer runs on the HIP kernels only: without a GPU it refuses to construct."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from alphapig_amd.train import HipTrainer
+    prm, _, _, _ = tiny_problem()
+    with pytest.raises(RuntimeError):
+        HipTrainer(prm, "resnet", n_blocks=1, batch_size=6)
