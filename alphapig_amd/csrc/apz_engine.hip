@@ -1286,7 +1286,9 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    const int slices = std::max(1, std::min(n, e->num_cu / T::GROUPS));       // 12 position groups x slices ~ one per CU
+    // 12 position groups x slices ~ two workgroups per CU, the groups of a slice on one XCD (see the kernel)
+    const int spx = std::max(1, std::min((n + 7) / 8, 2 * e->num_cu / (8 * T::GROUPS)));
+    const int slices = 8 * spx;
     if (slices > e->wgw_slices) {
         HIP_TRY(hipDeviceSynchronize());
         if (e->wgw_scratch) HIP_TRY(hipFree(e->wgw_scratch));
@@ -1300,8 +1302,8 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
                                     T::LDS_BYTES));
         attr = true;
     }
-    hipLaunchKernelGGL(apz::wgrad_wino_kernel, dim3(T::GROUPS, slices), dim3(512), T::LDS_BYTES, e->stream, (const float*)x_dev,
-                       (const float*)dy_dev, e->wgw_scratch, n);
+    hipLaunchKernelGGL(apz::wgrad_wino_kernel, dim3(T::GROUPS * slices), dim3(T::THREADS), T::LDS_BYTES, e->stream,
+                       (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
     hipLaunchKernelGGL(apz::wgrad_wino_sum_kernel, dim3(36 * 128 * 128 / 4 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
                        slices);
     hipLaunchKernelGGL(apz::wgrad_wino_reduce_kernel, dim3(128 * 128 / 256), dim3(256), 0, e->stream, e->wgw_scratch,

@@ -6,14 +6,25 @@
 // i.e. 36 independent [128 x K] x [K x 128] products with K = 16 tiles per board: 9 216 fp32 MFMAs per board
 // instead of the 32 832 of the direct form (conv3x3_wgrad_kernel).
 //
-// A workgroup owns SIX of the 36 positions (row i of the 6x6: 6 groups) for ALL 128 x 128 channel pairs
-// (wave w = output channels 16w.., all eight input-channel tiles: 192 accumulator registers) and a slice of
-// the batch.  Per board it streams the 128 input planes and the 128 output-gradient
-// planes through LDS in chunks of 16 + 16 (padded-row layout of the trunk), transforms each (channel, tile)
-// to its six positions (waves 0-3: V from 6x6 input patches, waves 4-7: dM from 4x4 gradient tiles) into
-// two LDS operand arrays [pos 6][tile 16][channel 128 (+16)], then issues 6 x 8 x 4 MFMAs per wave.  Partial dU
-// of the slices go to a scratch tensor; wgrad_wino_reduce_kernel sums them and applies G^T . G.
-// VALU work does not hide under fp32 MFMAs on this chip, so the phases are simply sequential.
+// A workgroup (4 waves) owns THREE of the 36 positions (half a row of the 6x6: 12 groups) for ALL 128 x 128 channel
+// pairs (wave = output-channel half x input-channel half: 3 x 4 x 4 accumulator tiles = 192 registers) and a slice
+// of the batch; TWO workgroups share a CU (78 KB of LDS and 256 registers per wave each), so that one is in its
+// transform phase (LDS, barriers, global latency) while the other feeds the matrix pipe.
+// Per board a workgroup streams the 128 input planes and the 128 output-gradient planes through LDS in chunks of
+// 8 + 8 planes, double-buffered and filled by LDS-DMA (global_load_lds_dwordx4: no staging registers -- with 192
+// accumulators every register spent on staging came back as a scratch spill, and a scratch reload waits for ALL
+// outstanding loads), transforms each (channel, tile) to its three positions (waves 0-1: V from 6x6 input patches,
+// waves 2-3: dM from 4x4 gradient tiles) into two LDS operand arrays [pos 3][channel group 8][tile 16][16 channels],
+// then issues 3 x 4 x 16 MFMAs per wave.  One barrier per chunk.  Partial dU of the slices go to a scratch tensor;
+// wgrad_wino_sum_kernel / wgrad_wino_reduce_kernel add them and apply G^T . G.
+//
+// Measured (MI355X, 512 boards): 219 us for the three kernels (the previous 8-wave / 6-position / register-staged
+// version: 292 us; the direct conv3x3_wgrad_kernel: 397 us).  Counters of the main kernel: matrix pipe busy 41 % of
+// the time, LDS array 26 % (bank conflicts 38 % of that), waves parked 44 %.  What bounds it now is the VALU
+// transform, which fp32 MFMAs do not overlap on this chip and which this decomposition repeats (every position row's
+// first stage is computed by two workgroups; the two input-transform waves of a workgroup carry 84 instructions per
+// unit against 30 of the gradient-transform waves).  An L2 touch of the chunks three ahead (4-byte LDS-DMA per line)
+// was tried and made it slower (235 us): the parked time is barrier skew between those roles, not DMA latency.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,177 +33,207 @@
 namespace apz {
 
 struct WgradWino {
-    static constexpr int C = 128, CK = 16, NCHUNK = C / CK;
+    static constexpr int C = 128, CK = 8, NCHUNK = C / CK;
     static constexpr int GPLANE = 240;
-    static constexpr int RROW = 20, RPS = 17 * RROW, RFRONT = 24;      // raw input tile: as trunk15_wino2.h
-    static constexpr int RAWX_FLOATS = RFRONT + CK * RPS;               // 5464
-    static constexpr int RAWY_FLOATS = CK * GPLANE + 16;                // 3856 (gradient planes as stored, + slack)
-    static constexpr int OPS = 144;                                     // operand row: 128 channels + 16 (bank spread)
-    static constexpr int NPOS = 6;                                      // positions per workgroup: one row of the 6x6
-    static constexpr int OP_FLOATS = NPOS * 16 * OPS;                   // 13824 per operand array
-    static constexpr int LDS_FLOATS = RAWX_FLOATS + RAWY_FLOATS + 2 * OP_FLOATS;   // 36968 floats = 144.4 KiB
+    static constexpr int RAW_FLOATS = CK * GPLANE;                      // 1920: the chunk's planes of one tensor, as stored
+    static constexpr int RAWBUF_FLOATS = 2 * RAW_FLOATS;                // input planes, then gradient planes
+    static constexpr int NPOS = 3;                                      // positions per workgroup: half a row of the 6x6
+    static constexpr int OP_FLOATS = NPOS * 8 * 16 * 16;                // 6144 per operand array
+    static constexpr int LDS_FLOATS = 2 * RAWBUF_FLOATS + 2 * OP_FLOATS;   // 19968 floats = 78 KiB
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
-    static constexpr int GROUPS = 6;
+    static constexpr int GROUPS = 12;
+    static constexpr int THREADS = 256;
     static constexpr size_t SCRATCH_FLOATS_PER_SLICE = (size_t)36 * C * C;
 };
+static_assert(2 * WgradWino::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
-// rows of B^T (6x6) and of A (6x4): the workgroup's position row / columns are runtime values, so the transforms
-// are plain coefficient dot products (a `switch` on the row made hipcc evaluate every case and select)
+// rows of B^T (6x6) and of A (6x4): the workgroup's position row is a runtime value, so the first transform stage is
+// a plain coefficient dot product (a `switch` on the row made hipcc evaluate every case and select)
 __device__ const float WGW_BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
                                        {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
 __device__ const float WGW_A[6][4] = {{1, 0, 0, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}, {1, 2, 4, 8}, {1, -2, 4, -8}, {0, 0, 0, 1}};
 
-// x, dy: padded-row layout [n][128][15][16].  scratch: [slices][36][128 co][128 ci].  grid (12 groups, slices).
-__global__ __launch_bounds__(512) void wgrad_wino_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                         float* __restrict__ scratch, int n) {
+// One wave-instruction of LDS-DMA: lane l copies 16 bytes from its global address to LDS byte lds_base + 16 l.
+// Inline assembly, so that hipcc's wait-count insertion does not see it (it would put vmcnt(0) in front of every LDS
+// read that might alias a DMA destination, i.e. wait for the chunk just requested); the kernel counts by hand.
+__device__ __forceinline__ void wgw_dma16(const float* gsrc_lane, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds_base) : "memory");
+}
+
+// lane k of every quad takes `v` of lane k-1 (DOWN) / k+1 (UP); the quad's ends get 0
+template <bool UP>
+__device__ __forceinline__ float wgw_quad_neighbour(float v, int k) {
+    const int moved = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), UP ? 0xf9 : 0x90, 0xf, 0xf, false);   // quad_perm [1,2,3,3] / [0,0,1,2]
+    return k == (UP ? 3 : 0) ? 0.f : __builtin_bit_cast(float, moved);
+}
+
+// GH = which half of the row (columns 3 GH .. 3 GH + 2): compile-time, so that zero coefficients of the second
+// transform stage cost nothing
+template <int GH>
+__device__ __forceinline__ void wgrad_wino_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                                float* __restrict__ scratch, int n, int gi, int slice, int slices, float* lds) {
     using T = WgradWino;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* rawx = lds;                               // [16 planes][17 rows x 20] + front
-    float* rawy = lds + T::RAWX_FLOATS;              // [16 planes][240]
-    float* opv = rawy + T::RAWY_FLOATS;              // V  [6][16 tiles][144]
-    float* opm = opv + T::OP_FLOATS;                 // dM [6][16 tiles][144]
+    float* raw = lds;                                // [2 buffers][8 input planes | 8 gradient planes][240]
+    float* opv = lds + 2 * T::RAWBUF_FLOATS;         // V  [3][8][16 tiles][16]
+    float* opm = opv + T::OP_FLOATS;                 // dM [3][8][16 tiles][16]
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, j = lane & 15;
-    const int gi = blockIdx.x;                       // transformed row i: the workgroup's positions are (i, 0..5)
-    const int wa = wave >> 2, wb = wave & 3;         // MFMA phase: output-channel half, input-channel quarter
+    const int wa = wave >> 1, wb = wave & 1;         // MFMA phase: output-channel half, input-channel half
 
-    for (int i = tid; i < T::RAWX_FLOATS; i += 512) rawx[i] = 0.f;   // halo cells stay zero
-
-    f32x4 acc[T::NPOS][8];
+    f32x4 acc[T::NPOS][4][4];
 #pragma unroll
     for (int p = 0; p < T::NPOS; p++)
 #pragma unroll
-        for (int t = 0; t < 8; t++) acc[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc[p][t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // transform roles: waves 0-3 -> input units, waves 4-7 -> gradient units; unit = (channel of the chunk, tile)
-    const int unit = tid & 255, uch = unit >> 4, utile = unit & 15, uty = utile >> 2, utx = utile & 3;
-    const bool is_x = tid < 256;
-    float cbr[6], car[4];                            // runtime coefficient rows: B^T row i, A row i
+    // transform roles: waves 0-1 -> input units, waves 2-3 -> gradient units; unit = (channel of the chunk, tile);
+    // the four tiles of a tile row are the four lanes of a quad
+    const int unit = tid & 127, uch = unit >> 4, utile = unit & 15, uty = utile >> 2, utx = utile & 3;
+    const bool is_x = wave < 2;
+    // first-stage rows with the board's edge folded in: the planes sit in LDS as stored (15 rows of 16, pad column
+    // zero), a row outside the board gets coefficient 0 and a clamped address
+    float cf[6];
+    int ro[6];
 #pragma unroll
-    for (int a = 0; a < 6; a++) cbr[a] = WGW_BT[gi][a];
-#pragma unroll
-    for (int a = 0; a < 4; a++) car[a] = WGW_A[gi][a];
+    for (int a = 0; a < 6; a++) {
+        const int r = is_x ? 4 * uty - 1 + a : 4 * uty + a;
+        const bool ok = r >= 0 && r < 15 && (is_x || a < 4);
+        cf[a] = ok ? (is_x ? WGW_BT[gi][a] : WGW_A[gi][a & 3]) : 0.f;
+        ro[a] = (is_x ? 0 : T::RAW_FLOATS) + uch * T::GPLANE + (ok ? r : 0) * 16 + 4 * utx;
+    }
     constexpr float cbc[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
                                  {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};      // B^T, all rows
     constexpr float cac[6][4] = {{1, 0, 0, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}, {1, 2, 4, 8}, {1, -2, 4, -8}, {0, 0, 0, 1}};
 
-    // staging pipeline: the 16 + 16 planes of a chunk are 2 x 960 pieces of 16 B = 4 per thread; the pieces of the
-    // TWO following chunks are in flight in registers (192 accumulators leave room for no more)
-    f32x4 pq[2][4];
-    // (every thread issues exactly four loads and four LDS stores per chunk, unconditionally -- past the end the last
-    // board is re-read, threads 448..511 repeat their first pieces -- so that hipcc can count vmcnt exactly: with a
-    // conditional load it waits for ALL outstanding loads at every use and the four-deep pipeline collapses)
-    const int v1 = tid < 448 ? tid + 512 : tid;
-    const int pl0 = tid / 60, k0 = tid - pl0 * 60, pl1 = v1 / 60, k1 = v1 - pl1 * 60;
-    const int dx0 = T::RFRONT + pl0 * T::RPS + (k0 >> 2) * T::RROW + (k0 & 3) * 4;
-    const int dx1 = T::RFRONT + pl1 * T::RPS + (k1 >> 2) * T::RROW + (k1 & 3) * 4;
-    auto fetch = [&](int bb, int cc, int slot) {
+    // a chunk = 2 x 7680 contiguous bytes in global memory = 2 x 7.5 DMA instructions of 1 KiB; wave w moves pieces
+    // w and w + 4 of either tensor (piece 7 is half a KiB: lanes 0-31)
+    auto issue = [&](int bb, int cc, int buf) {
         bb = bb < n ? bb : n - 1;
-        const f32x4* xs = reinterpret_cast<const f32x4*>(x + ((size_t)bb * T::C + cc * T::CK) * T::GPLANE);
-        const f32x4* ys = reinterpret_cast<const f32x4*>(dy + ((size_t)bb * T::C + cc * T::CK) * T::GPLANE);
-        pq[slot][0] = xs[tid];
-        pq[slot][1] = xs[v1];
-        pq[slot][2] = ys[tid];
-        pq[slot][3] = ys[v1];
+        const size_t off = ((size_t)bb * T::C + cc * T::CK) * T::GPLANE + wave * 256 + lane * 4;
+        const unsigned l0 = lds_base + buf * (T::RAWBUF_FLOATS * 4) + wave * 1024;
+        wgw_dma16(x + off, l0);
+        wgw_dma16(dy + off, l0 + T::RAW_FLOATS * 4);
+        if (wave < 3 || lane < 32) {
+            wgw_dma16(x + off + 1024, l0 + 4096);
+            wgw_dma16(dy + off + 1024, l0 + T::RAW_FLOATS * 4 + 4096);
+        }
     };
-    auto put = [&](int slot) {
-        *reinterpret_cast<f32x4*>(rawx + dx0) = pq[slot][0];
-        *reinterpret_cast<f32x4*>(rawx + dx1) = pq[slot][1];
-        reinterpret_cast<f32x4*>(rawy)[tid] = pq[slot][2];
-        reinterpret_cast<f32x4*>(rawy)[v1] = pq[slot][3];
-    };
-#pragma unroll
-    for (int d = 0; d < 2; d++) fetch((int)blockIdx.y, d, d);
+    issue(slice, 0, 0);
 
-    for (int b = blockIdx.y; b < n; b += gridDim.y) {
-        for (int half = 0; half < 4; half++) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int c = half * 2 + u;
-            __syncthreads();                         // previous chunk's raw tiles consumed (and the MFMA phase done)
-            put(u);
-            if (half < 3)
-                fetch(b, c + 2, u);                  // two chunks ahead: same board ...
+    for (int b = slice; b < n; b += slices) {
+#pragma unroll 2
+        for (int c = 0; c < T::NCHUNK; c++) {
+            const int buf = c & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c have landed ...
+            __syncthreads();                                    // ... everybody's have, and chunk c-1 (and the MFMA phase) is consumed
+            if (c + 1 < T::NCHUNK)
+                issue(b, c + 1, buf ^ 1);            // the next chunk of this board ...
             else
-                fetch(b + (int)gridDim.y, u, u);     // ... or the first chunks of this workgroup's next board
-            __syncthreads();
-            // ---- transform this chunk's units to the workgroup's three positions
+                issue(b + slices, 0, buf ^ 1);       // ... or the first chunk of this workgroup's next board
+            // ---- transform this chunk's units to the workgroup's three positions.  Operand rows are swizzled: channel
+            // ch of tile t sits at slot (ch & 15) ^ 2 (t >> 1) of its 16-channel group, which spreads the 32 lanes of a
+            // write (2 channels x 16 tiles; tiles are 16 banks apart) over 32 banks and permutes only within the 16
+            // channels that one MFMA operand read takes
+            const float* rb = raw + buf * T::RAWBUF_FLOATS;
+            const int wpos = ((c >> 1) * 16 + utile) * 16 + ((((c & 1) * 8) + uch) ^ (2 * (utile >> 1)));
             if (is_x) {
-                // the 6x6 patch row by row: column -1, columns 0..3 (one aligned 16-byte read), column 4
-                const float* rp = rawx + T::RFRONT + uch * T::RPS + (4 * uty - 1) * T::RROW + 4 * utx;
                 float r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // row i of B^T d, six columns
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
-                    const float cm1 = rp[a * T::RROW - 1];
-                    const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + a * T::RROW);
-                    const float c4 = rp[a * T::RROW + 4];
-                    r[0] = __builtin_fmaf(cbr[a], cm1, r[0]);
-                    r[1] = __builtin_fmaf(cbr[a], c03[0], r[1]);
-                    r[2] = __builtin_fmaf(cbr[a], c03[1], r[2]);
-                    r[3] = __builtin_fmaf(cbr[a], c03[2], r[3]);
-                    r[4] = __builtin_fmaf(cbr[a], c03[3], r[4]);
-                    r[5] = __builtin_fmaf(cbr[a], c4, r[5]);
+                    // columns 0..3 of the 6x6 patch are one 16-byte read; columns -1 and 4 are the neighbouring tiles'
+                    // columns 3 and 0, taken from the neighbouring lanes (as LDS reads they were 4-way bank-conflicted)
+                    const f32x4 c03 = *reinterpret_cast<const f32x4*>(rb + ro[a]);
+                    const float cm1 = wgw_quad_neighbour<false>(c03[3], utx);
+                    const float c4 = wgw_quad_neighbour<true>(c03[0], utx);
+                    r[0] = __builtin_fmaf(cf[a], cm1, r[0]);
+                    r[1] = __builtin_fmaf(cf[a], c03[0], r[1]);
+                    r[2] = __builtin_fmaf(cf[a], c03[1], r[2]);
+                    r[3] = __builtin_fmaf(cf[a], c03[2], r[3]);
+                    r[4] = __builtin_fmaf(cf[a], c03[3], r[4]);
+                    r[5] = __builtin_fmaf(cf[a], c4, r[5]);
                 }
 #pragma unroll
-                for (int kk = 0; kk < 6; kk++) {
+                for (int kk = 0; kk < T::NPOS; kk++) {
                     float o = 0.f;
 #pragma unroll
                     for (int k = 0; k < 6; k++)
-                        if (cbc[kk][k] != 0.f) o = __builtin_fmaf(cbc[kk][k], r[k], o);
-                    opv[(kk * 16 + utile) * T::OPS + c * T::CK + uch] = o;
+                        if (cbc[3 * GH + kk][k] != 0.f) o = __builtin_fmaf(cbc[3 * GH + kk][k], r[k], o);
+                    opv[kk * 2048 + wpos] = o;
                 }
             } else {
-                const float* yp = rawy + uch * T::GPLANE + (4 * uty) * 16 + 4 * utx;
                 f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};   // row i of A dY, four columns (one 16-byte read per tile row)
 #pragma unroll
-                for (int a = 0; a < 4; a++) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(yp + (4 * uty + a < 15 ? a : 0) * 16);
-                    r4 += (4 * uty + a < 15 ? car[a] : 0.f) * v;
-                }
+                for (int a = 0; a < 4; a++) r4 += cf[a] * *reinterpret_cast<const f32x4*>(rb + ro[a]);
                 const float r[4] = {r4[0], r4[1], r4[2], r4[3]};
 #pragma unroll
-                for (int kk = 0; kk < 6; kk++) {
+                for (int kk = 0; kk < T::NPOS; kk++) {
                     float o = 0.f;
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if (cac[kk][k] != 0.f) o = __builtin_fmaf(cac[kk][k], r[k], o);
-                    opm[(kk * 16 + utile) * T::OPS + c * T::CK + uch] = o;
+                        if (cac[3 * GH + kk][k] != 0.f) o = __builtin_fmaf(cac[3 * GH + kk][k], r[k], o);
+                    opm[kk * 2048 + wpos] = o;
                 }
             }
         }
-        }
         __syncthreads();                             // both operand arrays complete for board b
         // ---- dU[pos][co][ci] += dM[pos][co][tile] * V[pos][ci][tile]:  A = dM (m = co), B = V (n = ci), k = tile.
-        // wave = (co half wa: four 16-channel tiles, ci quarter wb: two tiles): 4 + 2 operand reads per 8 MFMAs
+        // wave = (co half wa, ci half wb): four 16-channel groups each way, 4 + 4 operand reads per 16 MFMAs
 #pragma unroll
         for (int p = 0; p < T::NPOS; p++)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const float* om = opm + (p * 16 + 4 * s + q) * T::OPS + wa * 64 + j;
-                const float* ov = opv + (p * 16 + 4 * s + q) * T::OPS + wb * 32 + j;
-                const float b0 = ov[0], b1 = ov[16];
+                const int slot = (4 * s + q) * 16 + (j ^ (4 * s + 2 * (q >> 1)));   // tile 4 s + q, swizzled channel slot
+                const float* om = opm + (p * 8 + wa * 4) * 256 + slot;
+                const float* ov = opv + (p * 8 + wb * 4) * 256 + slot;
+                float bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) bv[u] = ov[u * 256];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const float a = om[t * 16];
-                    acc[p][2 * t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[p][2 * t], 0, 0, 0);
-                    acc[p][2 * t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[p][2 * t + 1], 0, 0, 0);
+                    const float a = om[t * 256];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        acc[p][t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[u], acc[p][t][u], 0, 0, 0);
                 }
             }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) chunk request: a wave must not end with it in flight
     // ---- partial dU of this slice: accumulator (t, u), lane (q, j), register r -> co = 64 wa + 16 t + 4q + r,
-    // ci = 32 wb + 16 u + j
-    float* out = scratch + (size_t)blockIdx.y * T::SCRATCH_FLOATS_PER_SLICE;
+    // ci = 64 wb + 16 u + j
+    float* out = scratch + (size_t)slice * T::SCRATCH_FLOATS_PER_SLICE;
 #pragma unroll
     for (int p = 0; p < T::NPOS; p++) {
-        const int pos = gi * 6 + p;
+        const int pos = gi * 6 + 3 * GH + p;
 #pragma unroll
-        for (int t = 0; t < 8; t++)
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                out[((size_t)pos * T::C + wa * 64 + (t >> 1) * 16 + 4 * q + r) * T::C + wb * 32 + (t & 1) * 16 + j] = acc[p][t][r];
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    out[((size_t)pos * T::C + wa * 64 + t * 16 + 4 * q + r) * T::C + wb * 64 + u * 16 + j] = acc[p][t][u][r];
     }
+}
+
+// x, dy: padded-row layout [n][128][15][16].  scratch: [slices][36][128 co][128 ci].
+// Grid: 8 * 12 * spx workgroups (spx = batch slices per XCD, slices = 8 * spx).  The twelve position groups of a slice
+// read the SAME boards: workgroup L (dispatched round-robin, L mod 8 = its XCD) takes slice (L mod 8) * spx + (L / 8) / 12
+// and group (L / 8) mod 12, so the sharers sit on one XCD, run in step and all but one read of a board hit that
+// XCD's L2 -- spread over the XCDs every board crosses the fabric once per group.
+__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ scratch, int n, int spx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wg_k = blockIdx.x >> 3;
+    const int g = wg_k % WgradWino::GROUPS;          // position group: row g / 2 of the 6x6, columns 3 (g % 2) ..
+    const int slice = (blockIdx.x & 7) * spx + wg_k / WgradWino::GROUPS, slices = 8 * spx;
+    if (g & 1)
+        wgrad_wino_body<1>(x, dy, scratch, n, g >> 1, slice, slices, lds);
+    else
+        wgrad_wino_body<0>(x, dy, scratch, n, g >> 1, slice, slices, lds);
 }
 
 // stage 1: dU[pos][co][ci] = sum over slices (in place into slice 0); one thread per element, 16-byte accesses
