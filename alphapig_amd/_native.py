@@ -117,6 +117,28 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms"]
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP / HSA runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as
+    the system's): whichever copy is mapped first serves every later user.  If this library came first it would
+    pull in /opt/rocm's copy, a later `import torch` would map the wheel's copy as well (it is loaded by path), the
+    second HSA runtime finds no device and torch.cuda.is_available() turns False -- the trainer, which shares device
+    memory and streams with torch, could then not run in a process that had evaluated first.  So: when torch is
+    installed but not yet imported, map ITS runtime before ours (no `import torch`: that costs seconds)."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    lib = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(lib):
+        C.CDLL(lib, mode=C.RTLD_GLOBAL)
+
+
 def hip():
     """libalphapig_hip.so (include/alphapig_hip.h)."""
     global _hip
@@ -125,6 +147,7 @@ def hip():
     if not os.path.exists(HIP_LIB):
         raise NativeLibraryMissing(
             "%s not built; run `python -m alphapig_amd.build hip` (the evaluator has no CPU fallback)" % HIP_LIB)
+    _one_hip_runtime()
     L = C.CDLL(HIP_LIB)
     vp, f32p, u8p, i32p = C.c_void_p, _ptr(C.c_float), _ptr(C.c_uint8), _ptr(C.c_int32)
     sig = {

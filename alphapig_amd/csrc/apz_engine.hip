@@ -82,7 +82,7 @@ struct apz_engine {
     float *w6 = nullptr, *b6 = nullptr, *wfc_pk = nullptr, *bfc = nullptr, *wv = nullptr, *bv = nullptr;
     // device buffers
     float* act[3] = {nullptr, nullptr, nullptr};
-    float *planes = nullptr, *featp = nullptr, *featv = nullptr, *probs = nullptr, *values = nullptr;
+    float *planes = nullptr, *featp = nullptr, *featv = nullptr, *probs = nullptr, *values = nullptr, *fc_logits = nullptr;
     unsigned char* codes = nullptr;
     int *perm_s = nullptr, *perm_p = nullptr;
     // host pinned staging (apz_forward_host)
@@ -488,8 +488,8 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
     const int hw = e->hw;
     {
         Timed tm(e, APZ_K_HEAD_CONV);
-        if (e->ring && e->clast % 8 == 0)
-            hipLaunchKernelGGL(apz::head_conv1x1_r16_kernel, dim3((n + 3) / 4), dim3(256), 0, e->stream, trunk, e->w6, e->b6,
+        if (e->ring && e->clast % 32 == 0)
+            hipLaunchKernelGGL(apz::head_conv1x1_r16_kernel, dim3(n), dim3(256), 0, e->stream, trunk, e->w6, e->b6,
                                e->featp, e->featv, n, e->clast);
         else
             hipLaunchKernelGGL(apz::head_conv1x1_kernel, dim3(std::min(n, e->num_cu * 8)), dim3(256), 0, e->stream, trunk,
@@ -507,8 +507,12 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
             hipLaunchKernelGGL(apz::head_fc_kernel<1>, dim3(grid), dim3(256), lds, e->stream, e->featp, e->featv,
                                e->wfc_pk, e->bfc, e->wv, e->bv, probs, values, logits, vlogits, n, hw);
         } else if (tpw <= 4) {
-            hipLaunchKernelGGL(apz::head_fc_kernel<4>, dim3(grid), dim3(256), lds, e->stream, e->featp, e->featv,
-                               e->wfc_pk, e->bfc, e->wv, e->bv, probs, values, logits, vlogits, n, hw);
+            // the n-tiles over four workgroups per 16 boards, then one wavefront per board for softmax + value head
+            const int lds1 = 16 * (4 * hw + 1) * (int)sizeof(float);
+            hipLaunchKernelGGL((apz::head_fc_kernel<1, true>), dim3(grid, tpw), dim3(256), lds1, e->stream, e->featp, e->featv,
+                               e->wfc_pk, e->bfc, e->wv, e->bv, probs, values, logits, vlogits, n, hw, e->fc_logits);
+            hipLaunchKernelGGL(apz::head_softmax_value_kernel, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->fc_logits, e->featv,
+                               e->wv, e->bv, probs, values, logits, vlogits, n, hw, ntile * 16);
         } else {
             return fail(APZ_E_UNSUPPORTED, "policy head: board too large");
         }
@@ -568,7 +572,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch};
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -646,6 +650,7 @@ apz_engine* apz_create(const apz_config* cfg) {
     if ((err = hipMalloc((void**)&e->featp, B * 4 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->featv, B * 2 * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->probs, B * hw * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipMalloc((void**)&e->fc_logits, B * ((hw + 15) / 16 * 16) * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->values, B * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->codes, B * e->code_stride)) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipHostMalloc((void**)&e->h_planes, B * 9 * hw * sizeof(float))) != hipSuccess) return bail("hipHostMalloc", err);

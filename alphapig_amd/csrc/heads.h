@@ -65,48 +65,60 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   D  lane l, reg r: board = (l>>4)*4 + r, out = nt*16 + (l&15)
 // TPW = n-tiles per wave (ceil(NTILE / 4)); each wave keeps TPW independent accumulators so
 // the 40-cycle dependent-MFMA latency is covered.
-// The same two 1x1 head convolutions for the trunk's padded-row activations [n][C][15][16]: a thread owns one
-// 16-byte piece (4 pixels of a row) of a board and walks the C planes with 16-byte loads, eight in flight;
-// 4 boards per workgroup (240 of 256 threads).  Reads C*960 bytes per board once, coalesced.
+// The same two 1x1 head convolutions for the trunk's padded-row activations [n][C][15][16].  One workgroup per board;
+// wave w walks the planes of channel quarter w (C / 4 channels), lane k < 60 owning one 16-byte piece (4 pixels of a
+// row) with eight 16-byte loads in flight; the four partial sums meet in LDS and are added in quarter order.
+// (One thread per piece walking all C planes -- 4 boards per workgroup -- was 16 dependent load rounds on 128 of the
+// 256 CUs: 22 us per 512 boards for 63 MB.)  Reads C*960 bytes per board once, coalesced.
 __global__ __launch_bounds__(256) void head_conv1x1_r16_kernel(const float* __restrict__ x, const float* __restrict__ w6,
                                                                const float* __restrict__ b6, float* __restrict__ featp,
                                                                float* __restrict__ featv, int n, int C) {
-    const int t = threadIdx.x, sub = t / 60, k = t - sub * 60;
-    const int b = blockIdx.x * 4 + sub;
-    if (sub >= 4 || b >= n) return;
-    const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * C * 240) + k;
-    f32x4 acc[6];
+    __shared__ f32x4 part[4][6][60];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x, cq = C / 4;
+    if (lane < 60) {
+        const f32x4* xb = reinterpret_cast<const f32x4*>(x + ((size_t)b * C + wave * cq) * 240) + lane;
+        const float* wq = w6 + wave * cq;
+        f32x4 acc[6];
 #pragma unroll
-    for (int o = 0; o < 6; o++) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < C; c0 += 8) {
-        f32x4 v[8];
+        for (int o = 0; o < 6; o++) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < cq; c0 += 8) {
+            f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = xb[(size_t)(c0 + u) * 60];
+            for (int u = 0; u < 8; u++) v[u] = xb[(size_t)(c0 + u) * 60];
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 8; u++)
 #pragma unroll
-            for (int o = 0; o < 6; o++) acc[o] += w6[o * C + c0 + u] * v[u];
-    }
-    const int row = k >> 2, col0 = (k & 3) * 4;
-    float* fp = featp + (size_t)b * 4 * 225 + row * 15 + col0;
-    float* fv = featv + (size_t)b * 2 * 225 + row * 15 + col0;
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-        if (col0 + e < 15) {
-#pragma unroll
-            for (int o = 0; o < 4; o++) fp[o * 225 + e] = fmaxf(acc[o][e] + b6[o], 0.f);
-#pragma unroll
-            for (int o = 0; o < 2; o++) fv[o * 225 + e] = fmaxf(acc[4 + o][e] + b6[4 + o], 0.f);
+                for (int o = 0; o < 6; o++) acc[o] += wq[o * C + c0 + u] * v[u];
         }
+#pragma unroll
+        for (int o = 0; o < 6; o++) part[wave][o][lane] = acc[o];
+    }
+    __syncthreads();
+    if (lane >= 60) return;
+    const int row = lane >> 2, col0 = (lane & 3) * 4;
+    // wave w finishes output channels w and w + 4 (policy 0-3, value 4-5)
+    for (int o = wave; o < 6; o += 4) {
+        const f32x4 s = ((part[0][o][lane] + part[1][o][lane]) + part[2][o][lane]) + part[3][o][lane];
+        float* dst = (o < 4 ? featp + ((size_t)b * 4 + o) * 225 : featv + ((size_t)b * 2 + (o - 4)) * 225) + row * 15 + col0;
+        const float bo = b6[o];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (col0 + e < 15) dst[e] = fmaxf(s[e] + bo, 0.f);
+    }
 }
 
-template <int TPW>
+// SPLIT: the n-tiles are dealt over gridDim.y workgroups per 16 boards (wave w of workgroup y: tile 4 y + w, TPW = 1)
+// and the kernel ends with the biased logits in `logits_ws` [n][ntile * 16]; head_softmax_value_kernel finishes the
+// heads.  With one workgroup per 16 boards a 512-board batch ran on 32 of the 256 CUs, each streaming the whole
+// 810 KB weight matrix through 900 dependent MFMAs per wave (53 us); split four ways it is 128 workgroups x 225.
+template <int TPW, bool SPLIT = false>
 __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ featp, const float* __restrict__ featv,
                                                       const float* __restrict__ wfc_pk, const float* __restrict__ bfc,
                                                       const float* __restrict__ wv, const float* __restrict__ bv,
                                                       float* __restrict__ probs, float* __restrict__ values,
                                                       float* __restrict__ logits_out, float* __restrict__ vlogits_out,
-                                                      int n, int HW) {
+                                                      int n, int HW, float* __restrict__ logits_ws = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int K = 4 * HW, KS = HW;              // KS = K/4 k-steps
     const int ntile = (HW + 15) / 16;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
     auto load_trip = [&](int g, int buf) {
 #pragma unroll
         for (int i = 0; i < TPW; i++) {
-            const int nt = min(wave + 4 * i, ntile - 1);   // clamp: surplus tiles recompute the last one
+            const int nt = min((SPLIT ? 4 * (int)blockIdx.y : 0) + wave + 4 * i, ntile - 1);   // clamp: surplus tiles recompute the last one
             const f32x4* wp = reinterpret_cast<const f32x4*>(wfc_pk) + (((size_t)nt * KG + g) * 64 + lane) * 2;
             bw[buf][i][0] = wp[0];
             bw[buf][i][1] = wp[1];
@@ -184,6 +196,17 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
         mma_trip(g + 1, 1);
     }
     if (g < KG) mma_trip(g, 0);                 // odd trip count: its fragments are in buffer 0
+    if (SPLIT) {
+        const int nt = 4 * (int)blockIdx.y + wave;
+        if (nt < ntile) {
+            const int o = nt * 16 + j;
+            const float bb = (o < HW) ? bfc[o] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (q * 4 + r < nb) logits_ws[(size_t)(b0 + q * 4 + r) * ldl + o] = acc[0][r] + bb;
+        }
+        return;
+    }
     __syncthreads();            // features consumed; reuse LDS for the logits
     float* lg = sm;
 #pragma unroll
@@ -222,6 +245,55 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
             values[b0 + r] = tanhf(d);
             if (vlogits_out) vlogits_out[b0 + r] = d;
         }
+    }
+}
+
+// Second half of the split policy head: one wavefront per board -- row softmax of the logits head_fc_kernel<1, true>
+// left in logits_ws [n][ldl] (SoftmaxActivation, instance mode), and the value head (2*HW -> 1 dot product + tanh).
+__global__ __launch_bounds__(256) void head_softmax_value_kernel(const float* __restrict__ logits_ws, const float* __restrict__ featv,
+                                                                 const float* __restrict__ wv, const float* __restrict__ bv,
+                                                                 float* __restrict__ probs, float* __restrict__ values,
+                                                                 float* __restrict__ logits_out, float* __restrict__ vlogits_out,
+                                                                 int n, int HW, int ldl) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    // every load of the board is issued before the first reduction: one memory round trip instead of one per pass
+    // (HW <= 256: four logits per lane; 2 HW <= 512: eight value-head terms per lane)
+    const float* row = logits_ws + (size_t)r * ldl;
+    const float* fv = featv + (size_t)r * 2 * HW;
+    float l[4], f[8], w[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) l[i] = (lane + 64 * i < HW) ? row[lane + 64 * i] : -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int o = lane + 64 * i;
+        f[i] = o < 2 * HW ? fv[o] : 0.f;
+        w[i] = o < 2 * HW ? wv[o] : 0.f;
+    }
+    const float m = wave_max(fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3])));
+    float ex[4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ex[i] = (lane + 64 * i < HW) ? expf(l[i] - m) : 0.f;
+        s += ex[i];
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int o = lane + 64 * i;
+        if (o < HW) {
+            probs[(size_t)r * HW + o] = ex[i] * inv;
+            if (logits_out) logits_out[(size_t)r * HW + o] = l[i];
+        }
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d = fmaf(f[i], w[i], d);
+    d = wave_sum(d) + bv[0];
+    if (lane == 0) {
+        values[r] = tanhf(d);
+        if (vlogits_out) vlogits_out[r] = d;
     }
 }
 

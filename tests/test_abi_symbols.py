@@ -58,3 +58,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+
+
+def test_one_hip_runtime_per_process():
+    """Loading the HIP library before `import torch` must not leave two HIP runtimes in the process (the torch wheel
+    bundles its own libamdhip64.so; with two, the second finds no device and the trainer cannot run after the
+    evaluator): _native.hip() maps torch's copy first when torch is installed."""
+    import subprocess
+    import sys
+    code = ("import alphapig_amd._native as n\n"
+            "n.hip()\n"
+            "import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(len(libs), libs)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
