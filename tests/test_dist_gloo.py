@@ -100,3 +100,50 @@ def test_bench_starts_its_own_ranks(tmp_path):
     bad = subprocess.run(cmd, env=dict(env, APZ_BENCH_TEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=120)
     assert bad.returncode != 0 and "{" not in bad.stdout
+
+
+def test_eight_rank_rehearsal(tmp_path):
+    """BASELINE configs 4 / 5 shard the games over the 8 GPUs of a node.  The same code on 8 CPU ranks (gloo): every
+    global game index is played by exactly one rank (round-robin), with the seed of its index, and every rank ends
+    up with the same gathered tuples, rank-major."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    total, world = 19, 8
+    port = 33500 + random.randint(0, 2000)
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, "_dist_worker.py"),
+           str(tmp_path), str(total)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    ranks = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(world)]
+    assert sorted(int(i) for rk in ranks for i in rk["idx"]) == list(range(total))
+    for k, rk in enumerate(ranks):
+        assert list(rk["idx"]) == list(range(k, total, world))
+    for key in ("codes", "pis", "zs"):
+        want = np.concatenate([rk[key] for rk in ranks])
+        for k in range(world):
+            np.testing.assert_array_equal(np.load(tmp_path / ("gathered%d.npz" % k))[key], want)
+    # the same games as ONE engine plays them
+    eng = SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=4, n_playout=16, temp=1.0, base_seed=555,
+                         n_threads=1, pipeline=1, forced_opening=False)
+    eps = eng.play_games(total)
+    lens = {int(i): int(l) for rk in ranks for i, l in zip(rk["idx"], rk["lens"])}
+    assert [len(e.moves) for e in eps] == [lens[i] for i in range(total)]
+    eng.close()
+
+
+def test_bench_eight_self_spawned_ranks():
+    """`python bench.py --gpus 8` (the driver's N = 8 command shape) on CPU ranks: eight ranks come up, one line."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--plumbing-test"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["launcher"] == "self-spawned" and d["scaling"] == "weak"
+    assert d["host_threads_per_rank"] == max(1, min(16, d["host_cpu_share"] // 8))
