@@ -394,23 +394,31 @@ int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const 
     return launch_trunk_ring_t<4>(e, L, in, resid, out, n);
 }
 
-template <int C4, int CIN>
+template <int C4, int CIN, bool CODES>
 int launch_stem15_t(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
     constexpr int lds = apz::stem15_lds_bytes<C4>();
-    bool& configured = e->lds_attr_set[C4 == 1 ? 2 : 3];
+    bool& configured = e->lds_attr_set[(C4 == 1 ? 2 : 3) + (CODES ? 22 : 0)];
     if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::stem15_kernel<C4, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::stem15_kernel<C4, CIN, CODES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds));
         configured = true;
     }
     const int grid = std::min(n, e->num_cu * 2);   // two resident workgroups per CU
-    hipLaunchKernelGGL((apz::stem15_kernel<C4, CIN>), dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, out, n, L.cin);
+    hipLaunchKernelGGL((apz::stem15_kernel<C4, CIN, CODES>), dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, out, n,
+                       L.cin, (int)e->code_stride);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
 
-int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n) {
-    if (L.cin == 4) return launch_stem15_t<1, 4>(e, L, in, out, n);
-    if (L.cin == 9) return launch_stem15_t<3, 9>(e, L, in, out, n);
+// codes != nullptr: the stem reads the position codes itself (no planes buffer)
+int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out, int n, const unsigned char* codes = nullptr) {
+    if (codes) {
+        if (L.cin == 4) return launch_stem15_t<1, 4, true>(e, L, (const float*)codes, out, n);
+        if (L.cin == 9) return launch_stem15_t<3, 9, true>(e, L, (const float*)codes, out, n);
+    } else {
+        if (L.cin == 4) return launch_stem15_t<1, 4, false>(e, L, in, out, n);
+        if (L.cin == 9) return launch_stem15_t<3, 9, false>(e, L, in, out, n);
+    }
     return fail(APZ_E_UNSUPPORTED, "stem15: C_in must be 4 or 9");
 }
 
@@ -431,7 +439,7 @@ int launch_conv(apz_engine* e, const ConvLayer& L, const float* in, const float*
 }
 
 // runs conv layers [0, upto] on e->planes; returns the buffer holding layer `upto`'s output
-int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** result) {
+int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** result, const unsigned char* codes = nullptr) {
     float *x = e->act[0], *t = e->act[1], *y = e->act[2];
     const float* cur = planes;
     const int nl = (int)e->convs.size();
@@ -439,7 +447,8 @@ int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** resul
     {
         Timed tm(e, APZ_K_STEM);
         if (e->cfg.net_kind == APZ_NET_RESNET) {
-            int rc = launch_conv(e, e->convs[0], cur, nullptr, x, n);
+            int rc = (codes && e->ring) ? launch_stem15(e, e->convs[0], nullptr, x, n, codes)
+                                        : launch_conv(e, e->convs[0], cur, nullptr, x, n);
             if (rc) return rc;
             cur = x;
         } else {
@@ -476,14 +485,17 @@ int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** resul
     return APZ_OK;
 }
 
+// codes_dev != nullptr (stem_takes_codes(e) only): the position codes instead of `planes`
+bool stem_takes_codes(const apz_engine* e) { return e->ring && e->cfg.net_kind == APZ_NET_RESNET; }
+
 int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* values, float* logits,
-                float* vlogits) {
+                float* vlogits, const unsigned char* codes_dev = nullptr) {
     if (!e->loaded) return fail(APZ_E_STATE, "weights not loaded");
     if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
     if (n == 0) return APZ_OK;
     e->prof_now = e->profiling && (e->prof_phase++ % e->prof_stride == 0);
     float* trunk = nullptr;
-    int rc = run_trunk(e, planes, n, (int)e->convs.size() - 1, &trunk);
+    int rc = run_trunk(e, planes, n, (int)e->convs.size() - 1, &trunk, codes_dev);
     if (rc) return rc;
     const int hw = e->hw;
     {
@@ -834,9 +846,14 @@ int apz_forward_codes_async(apz_engine* e, const uint8_t* codes_pinned, int n, f
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t hw = e->hw;
     HIP_TRY(hipMemcpyAsync(e->codes, codes_pinned, (size_t)n * e->code_stride, hipMemcpyHostToDevice, e->stream));
-    int rc = apz_encode_planes(e, e->codes, n, e->cfg.c_in, e->planes);
-    if (rc) return rc;
-    rc = forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
+    int rc;
+    if (stem_takes_codes(e)) {
+        rc = forward_dev(e, nullptr, n, e->probs, e->values, nullptr, nullptr, e->codes);
+    } else {
+        rc = apz_encode_planes(e, e->codes, n, e->cfg.c_in, e->planes);
+        if (rc) return rc;
+        rc = forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
+    }
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(probs_pinned, e->probs, n * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(values_pinned, e->values, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -881,9 +898,14 @@ int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) 
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     std::memcpy(sl.h_codes, codes_host, (size_t)n * e->code_stride);
-    int rc = apz_encode_planes(e, sl.d_codes, n, e->cfg.c_in, e->planes);
-    if (rc) return rc;
-    rc = forward_dev(e, e->planes, n, sl.d_probs, sl.d_values, nullptr, nullptr);
+    int rc;
+    if (stem_takes_codes(e)) {      // the stem decodes the codes itself (read straight from the pinned slot)
+        rc = forward_dev(e, nullptr, n, sl.d_probs, sl.d_values, nullptr, nullptr, sl.d_codes);
+    } else {
+        rc = apz_encode_planes(e, sl.d_codes, n, e->cfg.c_in, e->planes);
+        if (rc) return rc;
+        rc = forward_dev(e, e->planes, n, sl.d_probs, sl.d_values, nullptr, nullptr);
+    }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(sl.done, e->stream));
     sl.n = n;

@@ -219,11 +219,15 @@ namespace apz {
 //     persistent workgroup: the board loop issues no weight loads at all;
 //   * input is the dense NCHW [n][C_in][15][15] planes buffer of the C ABI (the external
 //     contract), re-laid-out while staging.
+// CODES: `in` is not planes but the self-play path's position codes ([n][code_stride] bytes, heads.h
+//     encode_planes_kernel's input): the board's planes (Board.current_state, game.py:68-115, incl. the vertical flip)
+//     are built straight into the LDS tile -- the separate encode kernel, its 4 MB of planes and a launch disappear
+//     from the forward.
 // wpk: [8][C4][9][64]; out: rows16 [n][128][15][16].
-template <int C4, int CIN>
+template <int C4, int CIN, bool CODES = false>
 __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int n, int cin) {
+                                                        int n, int cin, int code_stride = 0) {
     using T = Trunk15;
     constexpr int NPL = 4 * C4;
     constexpr int LDSF = T::FRONT + NPL * T::LPS + 32;
@@ -251,13 +255,20 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
     const int lane_off = q * T::LPS + j - 17;
     const int total = cin * 225;
     constexpr int NPF = (CIN * 225 + 255) / 256;   // input floats per thread per board (4 or 8)
-    constexpr bool PREFETCH = (C4 == 1);           // C_in = 9 has no registers to spare (256-VGPR cap)
+    constexpr bool PREFETCH = (C4 == 1) || CODES;  // C_in = 9 planes: no registers to spare (256-VGPR cap); codes: two bytes
     // The stores of board b must drain WHILE board b+1 computes.  vmcnt retires in order, so
     // the next board's planes are loaded into registers BEFORE this board's stores are issued
     // (their wait then never covers a store), and the barriers protecting the LDS tile are raw
     // s_barrier + lgkmcnt(0): __syncthreads() would add vmcnt(0) and stall on the store acks.
-    float pf[NPF];
+    float pf[CODES ? 1 : NPF];
+    unsigned code = 0, colour = 0;                 // CODES: this thread's cell (tid < 225) and the board's colour byte
     auto prefetch = [&](int b) {
+        if (CODES) {
+            const unsigned char* cb = reinterpret_cast<const unsigned char*>(in) + (size_t)b * code_stride;
+            code = (b < n && tid < 225) ? cb[tid] : 0;
+            colour = b < n ? cb[225] : 0;
+            return;
+        }
         const float* src = in + (size_t)b * total;
 #pragma unroll
         for (int u = 0; u < NPF; u++) {
@@ -273,13 +284,37 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
     prefetch(blockIdx.x);
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         if (!PREFETCH && b != (int)blockIdx.x) prefetch(b);
+        if (CODES) {
+            if (tid < 225) {                      // cell m = tid of the un-flipped board -> row 14 - h of the planes
+                const int h = tid / 15, w = tid - h * 15;
+                float* cell = tile + (14 - h) * 16 + w;
+                const bool opp = code >= 5;
+                const int age = (code - 1) & 3;
+                const float col = colour ? 1.f : 0.f;
+                if (CIN == 9) {
 #pragma unroll
-        for (int u = 0; u < NPF; u++) {
-            const int idx = tid + u * 256;
-            if (idx < total) {
-                const int c = idx / 225, rem = idx - c * 225;
-                const int y = rem / 15, x = rem - y * 15;
-                tile[c * T::LPS + y * 16 + x] = pf[u];
+                    for (int k = 0; k < 4; k++) {
+                        const float on = (code && k <= age) ? 1.f : 0.f;
+                        cell[(6 - 2 * k) * T::LPS] = opp ? 0.f : on;
+                        cell[(7 - 2 * k) * T::LPS] = opp ? on : 0.f;
+                    }
+                    cell[8 * T::LPS] = col;
+                } else {
+                    cell[0 * T::LPS] = (code && !opp) ? 1.f : 0.f;
+                    cell[1 * T::LPS] = (code && opp) ? 1.f : 0.f;
+                    cell[2 * T::LPS] = (code && age == 0) ? 1.f : 0.f;
+                    cell[3 * T::LPS] = col;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NPF; u++) {
+                const int idx = tid + u * 256;
+                if (idx < total) {
+                    const int c = idx / 225, rem = idx - c * 225;
+                    const int y = rem / 15, x = rem - y * 15;
+                    tile[c * T::LPS + y * 16 + x] = pf[u];
+                }
             }
         }
         lds_barrier();
