@@ -111,7 +111,7 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_conv3x3_fwd", "apz_conv3x3_wgrad", "apz_wino_packed_size", "apz_wino_pack", "apz_wino_conv",
                "apz_wino_conv_add", "apz_bn_fwd", "apz_bn_bwd", "apz_adam_step", "apz_wgrad_wino",
                "apz_conv1x1_fwd", "apz_conv1x1_bwd", "apz_fc_fwd", "apz_fc_bwd", "apz_dropout", "apz_pv_loss",
-               "apz_layout_convert", "apz_bias_grad", "apz_add",
+               "apz_layout_convert", "apz_bias_grad", "apz_add", "apz_load_weights_dev",
                "apz_sync", "apz_stream",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
                "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms"]
@@ -195,6 +195,7 @@ def hip():
         "apz_layout_convert": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
         "apz_bias_grad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "apz_add": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+        "apz_load_weights_dev": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, vp]),
         "apz_sync": (C.c_int, [vp]),
         "apz_stream": (vp, [vp]),
         "apz_device_alloc": (vp, [vp, C.c_int64]),

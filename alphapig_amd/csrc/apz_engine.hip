@@ -24,6 +24,7 @@
 #include "sampler.h"
 #include "conv_train.h"
 #include "heads_train.h"
+#include "weights_pack.h"
 
 namespace {
 
@@ -117,6 +118,7 @@ struct apz_engine {
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     double* bn_sums = nullptr;                     // apz_bn_fwd / _bwd: per-channel reduction scratch
     float* wgw_scratch = nullptr;                  // apz_wgrad_wino: partial dU per batch slice
+    double* fold_ws = nullptr;                     // apz_load_weights_dev: scale / shift of one layer (2 x 256 doubles)
     float* head_scratch = nullptr;                 // apz_conv1x1_bwd / apz_pv_loss: per-board partial sums
     size_t head_scratch_floats = 0;
     int wgw_slices = 0;
@@ -584,7 +586,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits};
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -1025,6 +1027,82 @@ struct StreamScope {      // run the engine's launch helpers on a caller-supplie
     ~StreamScope() { e->stream = saved; }
 };
 }  // namespace
+
+// The same as apz_load_weights for tensors that already live in DEVICE memory (the trainer's): folding and packing run
+// as kernels on `stream` (APZ_ENGINE_STREAM: the engine's own), and the engine's stream waits for them.
+int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* const* dev_ptrs, const int64_t* sizes, int n,
+                         void* stream) {
+    if (!e || !names || !dev_ptrs || !sizes) return fail(APZ_E_ARG, "null argument");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (!e->loaded) return fail(APZ_E_STATE, "apz_load_weights_dev refreshes a loaded engine: call apz_load_weights first");
+    std::map<std::string, const float*> P;
+    std::map<std::string, int64_t> S;
+    for (int i = 0; i < n; i++) {
+        P[names[i]] = (const float*)dev_ptrs[i];
+        S[names[i]] = sizes[i];
+    }
+    for (auto& p : e->params) {
+        auto it = S.find(p.name);
+        if (it == S.end()) return fail(APZ_E_ARG, "missing parameter " + p.name);
+        if (it->second != p.size)
+            return fail(APZ_E_ARG, "parameter " + p.name + " has " + std::to_string(it->second) + " elements, expected " +
+                                       std::to_string(p.size));
+    }
+    hipStream_t engine_stream = e->stream;
+    {
+        StreamScope sc(e, stream);
+        hipStream_t st = e->stream;
+        if (!e->fold_ws) HIP_TRY(hipMalloc((void**)&e->fold_ws, 2 * 256 * sizeof(double)));
+        if (st != engine_stream) {      // forwards already queued on the engine's stream still read the old weights
+            hipEvent_t ev = get_event(e);
+            HIP_TRY(hipEventRecord(ev, engine_stream));
+            HIP_TRY(hipStreamWaitEvent(st, ev, 0));
+            e->free_events.push_back(ev);
+        }
+        double* scale = e->fold_ws;
+        double* shift = e->fold_ws + 256;
+        auto fold = [&](const std::string& conv, const std::string& bn, const std::string& mean_sfx, const std::string& var_sfx,
+                        bool fix_gamma, int cout, float* bias_out) {
+            hipLaunchKernelGGL(apz::fold_bn_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, P.at(conv + "_bias"),
+                               fix_gamma ? (const float*)nullptr : P.at(bn + "_gamma"), P.at(bn + "_beta"), P.at(bn + mean_sfx),
+                               P.at(bn + var_sfx), scale, shift, bias_out, cout, (double)BN_EPS);
+        };
+        for (auto& L : e->convs) {
+            if (L.cout > 256) return fail(APZ_E_UNSUPPORTED, "load_weights_dev: more than 256 channels");
+            fold(L.name, L.bn, L.mean_sfx, L.var_sfx, L.fix_gamma, L.cout, L.bias);
+            const float* w = P.at(L.name + "_weight");
+            const int n4 = L.cin_pad / 4, ncot = L.cout / 16;
+            const bool x4 = e->ring && &L != &e->convs[0];
+            const int total = ncot * n4 * 9 * 64;
+            hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale, L.wpk,
+                               L.cin, n4, ncot, (int)x4);
+            if (x4)
+                hipLaunchKernelGGL(apz::pack_wino_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale, L.upk, L.upk2);
+        }
+        const int C = e->clast, hw = e->hw;
+        fold("conv3_1_1", "conv3_1_1", "_mean", "_var", true, 4, nullptr);
+        hipLaunchKernelGGL(apz::pack_head_conv_kernel, dim3((4 * C + 255) / 256), dim3(256), 0, st, P.at("conv3_1_1_weight"), scale,
+                           shift, e->w6, e->b6, 4, 0, C);
+        fold("conv3_2_1", "conv3_2_1", "_mean", "_var", true, 2, nullptr);
+        hipLaunchKernelGGL(apz::pack_head_conv_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, P.at("conv3_2_1_weight"), scale,
+                           shift, e->w6, e->b6, 2, 4, C);
+        const int ntile = (hw + 15) / 16, KG = (hw + 7) / 8;
+        hipLaunchKernelGGL(apz::pack_fc_kernel, dim3(std::min((ntile * KG * 512 + 255) / 256, 2048)), dim3(256), 0, st,
+                           P.at("fc_3_1_1_weight"), e->wfc_pk, hw, ntile, KG);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(e->bfc, P.at("fc_3_1_1_bias"), hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e->wv, P.at("fc_3_2_1_weight"), 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e->bv, P.at("fc_3_2_1_bias"), sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (st != engine_stream) {      // forwards queued on the engine's stream from now on see the new weights
+            hipEvent_t ev = get_event(e);
+            HIP_TRY(hipEventRecord(ev, st));
+            HIP_TRY(hipStreamWaitEvent(engine_stream, ev, 0));
+            e->free_events.push_back(ev);
+        }
+    }
+    return APZ_OK;
+}
 
 int apz_conv3x3_pack(apz_engine* e, const void* w_dev, int cin, int cout, int transpose_flip, void* wpk_dev,
                      void* stream) {

@@ -161,6 +161,9 @@ class _KeepTrainer(object):
     def set_params(self, prm):
         self.net.set_params(prm, _keep_trainer=True)
 
+    def load_device_params(self, tensors, stream=None):
+        self.net.load_device_params(tensors, stream)
+
 
 class _NoPlayer(object):
     def reset_player(self):

@@ -93,9 +93,34 @@ class PolicyValueNet(object):
             sizes[i] = a.size
         self._ck(self.L.apz_load_weights(self._h, names, ptrs, sizes, len(table)))
         self._params = {name: keep[i].copy() for i, (name, _) in enumerate(table)}
+        self._device_source = None
+
+    def load_device_params(self, tensors, stream=None):
+        """Refresh the evaluator from parameters that already live in device memory -- {name: tensor with .data_ptr()
+        and .numel()}, e.g. the trainer's after an optimiser step: BatchNorm folding and weight packing run as kernels
+        (apz_load_weights_dev), nothing crosses PCIe.  The host-side copy behind params() is fetched lazily."""
+        table = self.param_table()
+        names = (C.c_char_p * len(table))()
+        ptrs = (C.c_void_p * len(table))()
+        sizes = (C.c_int64 * len(table))()
+        for i, (name, size) in enumerate(table):
+            if name not in tensors:
+                raise EvaluatorError("missing parameter %s" % name)
+            t = tensors[name]
+            if not t.is_contiguous():
+                raise EvaluatorError("parameter %s is not contiguous" % name)
+            names[i] = name.encode()
+            ptrs[i] = t.data_ptr()
+            sizes[i] = t.numel()
+        self._ck(self.L.apz_load_weights_dev(self._h, names, ptrs, sizes, len(table), C.c_void_p(stream)))
+        self._device_source = tensors
 
     def params(self):
         """{name: float32 array} of every parameter and BatchNorm statistic (one flat table)."""
+        src = getattr(self, "_device_source", None)
+        if src is not None:                # weights came from device tensors: fetch them once
+            self._params = {name: src[name].detach().cpu().numpy().astype(np.float32).copy() for name, _ in self.param_table()}
+            self._device_source = None
         return dict(self._params)
 
     def get_policy_param(self):
@@ -103,7 +128,7 @@ class PolicyValueNet(object):
         (policy_value_net_mxnet.py:301-303): BatchNorm moving statistics are the aux states."""
         from . import mxnet_model
         arg, aux = {}, {}
-        for k, v in self._params.items():
+        for k, v in self.params().items():
             (aux if k.endswith(mxnet_model.AUX_SUFFIXES) else arg)[k] = v.copy()
         return arg, aux
 
@@ -114,9 +139,9 @@ class PolicyValueNet(object):
         weights.load_params reads both."""
         if fmt == "mxnet":
             from . import mxnet_model
-            mxnet_model.save_model(self._params, model_file)
+            mxnet_model.save_model(self.params(), model_file)
         elif fmt == "flat":
-            weights.save_params(self._params, model_file)
+            weights.save_params(self.params(), model_file)
         else:
             raise ValueError("fmt must be 'mxnet' or 'flat'")
 
@@ -238,10 +263,10 @@ class PolicyValueNet(object):
         SURVEY.md 8f rank 1); the self-play hot path never touches them."""
         from .train import HipTrainer
         if getattr(self, "_trainer", None) is None:
-            self._trainer = HipTrainer(self._params, self.net_kind, self._n_blocks, batch_size=self.batchsize,
+            self._trainer = HipTrainer(self.params(), self.net_kind, self._n_blocks, batch_size=self.batchsize,
                                        device_index=self._device)
         loss, entropy = self._trainer.train_step(state_batch, mcts_probs, winner_batch, learning_rate)
-        self.set_params(self._trainer.get_params(), _keep_trainer=True)
+        self._trainer.sync_evaluator(self)
         return np.array([loss], dtype=np.float32), np.array([entropy], dtype=np.float32)
 
     # ---- measurement hooks

@@ -218,6 +218,12 @@ class HipTrainer(object):
         l3 = loss3.cpu().numpy()           # the step's only device -> host copy (12 bytes), and its synchronisation
         return float(l3[0] + l3[1]), float(l3[2])
 
+    def sync_evaluator(self, net):
+        """Give `net` (a PolicyValueNet of the same architecture) this trainer's current weights, device to device:
+        folding and packing run as kernels behind the optimiser step on the same stream (apz_load_weights_dev)."""
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        net.load_device_params(self.p, stream)
+
     def policy_value(self, state_batch):
         """Inference-mode (moving statistics) probabilities and values for the KL monitor: the self-play path's own
         evaluator (PolicyValueNet) on the current weights."""
@@ -229,7 +235,7 @@ class HipTrainer(object):
                                         device=self.device.index or 0)
             self._eval_t = self.t
         elif self._eval_t != self.t:
-            self._eval.set_params(self.get_params())
+            self.sync_evaluator(self._eval)
             self._eval_t = self.t
         return self._eval.policy_value(state_batch)
 
@@ -259,7 +265,10 @@ def policy_update(trainer, mini_batch, learn_rate=1e-3, lr_multiplier=1.0, epoch
     for _ in range(epochs):
         loss, entropy = trainer.train_step(states, pis, zs, learn_rate * lr_multiplier)
         if evaluator is not None:
-            evaluator.set_params(trainer.get_params())
+            if hasattr(trainer, "sync_evaluator") and hasattr(evaluator, "load_device_params"):
+                trainer.sync_evaluator(evaluator)
+            else:
+                evaluator.set_params(trainer.get_params())
         new_probs, new_v = pv(states)
         kl = float(np.mean(np.sum(old_probs * (np.log(old_probs + 1e-10) - np.log(new_probs + 1e-10)), axis=1)))
         if kl > kl_targ * 4:

@@ -203,6 +203,12 @@ int apz_bn_bwd(apz_engine *e, const void *dy_dev, const void *x_dev, const void 
  *                            pad cells of a padded-row gradient are zero), fixed summation order
  *   apz_add                  y += x (count floats): the meeting point of the trunk and skip gradients
  * conv1x1_bwd: dx gets zero pad cells; accumulate_dx != 0 adds to what dx already holds (second head). */
+/* apz_load_weights for tensors that already live in device memory (policy_value_net_mxnet.py:295-297: after an
+ * optimiser step the new parameters go into the predict modules): BatchNorm folding and every packing of
+ * apz_load_weights as kernels on `stream`; forwards queued afterwards use the new weights.  Same name / size table as
+ * apz_load_weights; the engine must have been loaded once from the host. */
+int apz_load_weights_dev(apz_engine *e, const char *const *names, const void *const *dev_ptrs, const int64_t *sizes,
+                         int n, void *stream);
 int apz_conv1x1_fwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *bias_dev, void *y_dev, int n,
                     int C, int CO, int layout, void *stream);
 int apz_conv1x1_bwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *dy_dev, void *dx_dev,

@@ -414,3 +414,38 @@ def test_policy_update_on_the_hip_trainer():
     assert loss < first
     assert 0.05 / 1.5 <= mult <= 20 * 1.5
     tr.close()
+
+
+@pytest.mark.parametrize("kind,side,blocks,nf", [("resnet", 15, 3, 128), ("simple", 8, 0, 128), ("resnet", 8, 2, 64)])
+def test_device_side_weight_refresh_equals_host_load(kind, side, blocks, nf):
+    """apz_load_weights_dev (BatchNorm folding, direct / Winograd / head / FC packing as kernels on the trainer's
+    device tensors) against apz_load_weights from the host: the two evaluators answer alike, and the device-loaded one
+    hands back the same parameter table."""
+    from alphapig_amd import weights
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    rs = np.random.RandomState(3)
+    prm = weights.init_params(kind, side, side, 9, blocks, nf, seed=5, style="bench")
+    other = weights.init_params(kind, side, side, 9, blocks, nf, seed=6, style="bench")
+    states = (rs.rand(20, 9, side, side) > 0.6).astype(np.float32)
+    host = PolicyValueNet(side, side, batch_size=32, n_blocks=blocks, n_filter=nf, model_params=prm, net_kind=kind)
+    dev = PolicyValueNet(side, side, batch_size=32, n_blocks=blocks, n_filter=nf, model_params=other, net_kind=kind)
+    p_other, _ = dev.policy_value(states)
+    tensors = {k: torch.tensor(np.ascontiguousarray(v, dtype=np.float32), device="cuda") for k, v in prm.items()}
+    dev.load_device_params(tensors, torch.cuda.current_stream().cuda_stream)
+    p_host, v_host = host.policy_value(states)
+    p_dev, v_dev = dev.policy_value(states)
+    assert np.abs(p_other - p_host).max() > 1e-4                     # the refresh changed something
+    # same double-precision maps; the device code contracts a*b+c into fma, so single results may differ by an ulp
+    np.testing.assert_allclose(p_dev, p_host, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(v_dev, v_host, rtol=0, atol=2e-6)
+    got = dev.params()
+    assert set(got) == set(prm)
+    for k in prm:
+        np.testing.assert_array_equal(got[k], prm[k].astype(np.float32), err_msg=k)
+    # a missing or mis-sized tensor is refused like on the host path
+    bad = dict(tensors)
+    bad.pop("fc_3_1_1_bias")
+    with pytest.raises(Exception):
+        dev.load_device_params(bad)
+    host.close()
+    dev.close()
