@@ -11,35 +11,39 @@
 // of the batch; TWO workgroups share a CU (78 KB of LDS and 256 registers per wave each), so that one is in its
 // transform phase (LDS, barriers, global latency) while the other feeds the matrix pipe.
 // Per board a workgroup streams the 128 input planes and the 128 output-gradient planes through LDS in chunks of
-// 8 + 8 planes, double-buffered and filled by LDS-DMA (global_load_lds_dwordx4: no staging registers -- with 192
+// 16 planes (input and gradient chunks alternate), double-buffered and filled by LDS-DMA (global_load_lds_dwordx4: no staging registers -- with 192
 // accumulators every register spent on staging came back as a scratch spill, and a scratch reload waits for ALL
-// outstanding loads), transforms each (channel, tile) to its three positions (waves 0-1: V from 6x6 input patches,
-// waves 2-3: dM from 4x4 gradient tiles) into two LDS operand arrays [pos 3][channel group 8][tile 16][16 channels],
+// outstanding loads), transforms each (channel, tile) to its three positions (V from 6x6 input patches in the input
+// chunks, dM from 4x4 gradient tiles in the gradient chunks; all four waves alike) into two LDS operand arrays [pos 3][channel group 8][tile 16][16 channels],
 // then issues 3 x 4 x 16 MFMAs per wave.  One barrier per chunk.  Partial dU of the slices go to a scratch tensor;
 // wgrad_wino_sum_kernel / wgrad_wino_reduce_kernel add them and apply G^T . G.
 //
-// Measured (MI355X, 512 boards): 219 us for the three kernels (the previous 8-wave / 6-position / register-staged
-// version: 292 us; the direct conv3x3_wgrad_kernel: 397 us).  Counters of the main kernel: matrix pipe busy 41 % of
+// Measured (MI355X, 512 boards, operands cache-resident): 206 us for the three kernels, 241 us with operands from HBM
+// (the previous 8-wave / 6-position / register-staged version: 292 us; the direct conv3x3_wgrad_kernel: 397 us).  Counters of the main kernel: matrix pipe busy 41 % of
 // the time, LDS array 26 % (bank conflicts 38 % of that), waves parked 44 %.  What bounds it now is the VALU
 // transform, which fp32 MFMAs do not overlap on this chip and which this decomposition repeats (every position row's
-// first stage is computed by two workgroups; the two input-transform waves of a workgroup carry 84 instructions per
-// unit against 30 of the gradient-transform waves).  An L2 touch of the chunks three ahead (4-byte LDS-DMA per line)
-// was tried and made it slower (235 us): the parked time is barrier skew between those roles, not DMA latency.
+// first stage is computed by two workgroups).  An L2 touch of the chunks a few ahead (4-byte LDS-DMA per line,
+// APZ_WGW_TOUCH) was tried twice and is slower with cache-resident and with HBM-resident operands (+20 us).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "conv3x3_mfma.h"
 
+#ifndef APZ_WGW_TOUCH
+#define APZ_WGW_TOUCH 0
+#endif
+
 namespace apz {
 
 struct WgradWino {
-    static constexpr int C = 128, CK = 8, NCHUNK = C / CK;
+    static constexpr int C = 128, CK = 16, NCHUNK = 2 * C / CK;       // 16 chunks per board: 8 input, 8 gradient
     static constexpr int GPLANE = 240;
-    static constexpr int RAW_FLOATS = CK * GPLANE;                      // 1920: the chunk's planes of one tensor, as stored
-    static constexpr int RAWBUF_FLOATS = 2 * RAW_FLOATS;                // input planes, then gradient planes
+    static constexpr int RAWBUF_FLOATS = CK * GPLANE;                   // 3840: the chunk's 16 planes, as stored
     static constexpr int NPOS = 3;                                      // positions per workgroup: half a row of the 6x6
     static constexpr int OP_FLOATS = NPOS * 8 * 16 * 16;                // 6144 per operand array
-    static constexpr int LDS_FLOATS = 2 * RAWBUF_FLOATS + 2 * OP_FLOATS;   // 19968 floats = 78 KiB
+    static constexpr int JUNK_FLOATS = 256;                             // landing zone of the L2 touches (never read)
+    static constexpr int LDS_FLOATS = 2 * RAWBUF_FLOATS + 2 * OP_FLOATS + JUNK_FLOATS;   // 20224 floats = 79 KiB
+    static constexpr int TOUCH_AHEAD = 4;                               // chunks between a touch and its use
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int GROUPS = 12;
     static constexpr int THREADS = 256;
@@ -59,6 +63,11 @@ __device__ const float WGW_A[6][4] = {{1, 0, 0, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}
 __device__ __forceinline__ void wgw_dma16(const float* gsrc_lane, unsigned lds_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds_base) : "memory");
 }
+// ... and of 4 bytes per lane: pulls the 128-byte lines of a later chunk into this XCD's L2 (one lane per line); the
+// bytes land in a junk area of LDS, so no register waits for them
+__device__ __forceinline__ void wgw_touch(const float* gsrc_lane, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc_lane), "s"(lds_base) : "memory");
+}
 
 // lane k of every quad takes `v` of lane k-1 (DOWN) / k+1 (UP); the quad's ends get 0
 template <bool UP>
@@ -73,7 +82,7 @@ template <int GH>
 __device__ __forceinline__ void wgrad_wino_body(const float* __restrict__ x, const float* __restrict__ dy,
                                                 float* __restrict__ scratch, int n, int gi, int slice, int slices, float* lds) {
     using T = WgradWino;
-    float* raw = lds;                                // [2 buffers][8 input planes | 8 gradient planes][240]
+    float* raw = lds;                                // [2 buffers][16 planes][240]
     float* opv = lds + 2 * T::RAWBUF_FLOATS;         // V  [3][8][16 tiles][16]
     float* opm = opv + T::OP_FLOATS;                 // dM [3][8][16 tiles][16]
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
@@ -91,72 +100,91 @@ __device__ __forceinline__ void wgrad_wino_body(const float* __restrict__ x, con
 #pragma unroll
             for (int u = 0; u < 4; u++) acc[p][t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // transform roles: waves 0-1 -> input units, waves 2-3 -> gradient units; unit = (channel of the chunk, tile);
-    // the four tiles of a tile row are the four lanes of a quad
-    const int unit = tid & 127, uch = unit >> 4, utile = unit & 15, uty = utile >> 2, utx = utile & 3;
-    const bool is_x = wave < 2;
-    // first-stage rows with the board's edge folded in: the planes sit in LDS as stored (15 rows of 16, pad column
-    // zero), a row outside the board gets coefficient 0 and a clamped address
-    float cf[6];
-    int ro[6];
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        const int r = is_x ? 4 * uty - 1 + a : 4 * uty + a;
-        const bool ok = r >= 0 && r < 15 && (is_x || a < 4);
-        cf[a] = ok ? (is_x ? WGW_BT[gi][a] : WGW_A[gi][a & 3]) : 0.f;
-        ro[a] = (is_x ? 0 : T::RAW_FLOATS) + uch * T::GPLANE + (ok ? r : 0) * 16 + 4 * utx;
-    }
+    // transform roles: the chunks alternate between 16 input planes and 16 gradient planes, and in every chunk all
+    // four waves do the same thing (256 units = (channel of the chunk, tile); the four tiles of a tile row are the
+    // four lanes of a quad).  With input and gradient units on different waves of one chunk the gradient waves (30
+    // instructions per unit against 84) spent most of every chunk at the barrier.
+    const int uch = tid >> 4, utile = tid & 15, uty = utile >> 2, utx = utile & 3;
+    // First-stage rows with the board's edge folded in: the planes sit in LDS as stored (15 rows of 16, pad column
+    // zero); a row outside the board gets coefficient 0 and the address of row 14 / row 0.  Only rows 0, 4, 5 of an
+    // input patch and row 3 of a gradient tile can fall outside: the other coefficients are wave-uniform.
+    const int xbase = uch * T::GPLANE + (4 * uty - 1) * 16 + 4 * utx, ybase = uch * T::GPLANE + 4 * uty * 16 + 4 * utx;
+    const int xo0 = xbase + (uty == 0 ? 16 : 0), xo4 = xbase + 64 - (uty == 3 ? 16 : 0), xo5 = xbase + 80 - (uty == 3 ? 32 : 0);
+    const int yo3 = ybase + 48 - (uty == 3 ? 16 : 0);
+    const float cx0 = uty == 0 ? 0.f : WGW_BT[gi][0], cx4 = uty == 3 ? 0.f : WGW_BT[gi][4], cx5 = uty == 3 ? 0.f : WGW_BT[gi][5];
+    const float cx1 = WGW_BT[gi][1], cx2 = WGW_BT[gi][2], cx3 = WGW_BT[gi][3];
+    const float cy0 = WGW_A[gi][0], cy1 = WGW_A[gi][1], cy2 = WGW_A[gi][2], cy3 = uty == 3 ? 0.f : WGW_A[gi][3];
     constexpr float cbc[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
                                  {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};      // B^T, all rows
     constexpr float cac[6][4] = {{1, 0, 0, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}, {1, 2, 4, 8}, {1, -2, 4, -8}, {0, 0, 0, 1}};
 
-    // a chunk = 2 x 7680 contiguous bytes in global memory = 2 x 7.5 DMA instructions of 1 KiB; wave w moves pieces
-    // w and w + 4 of either tensor (piece 7 is half a KiB: lanes 0-31)
+    // chunk cc of a board = 16 planes of ONE tensor (even: input channels 8 cc .., odd: gradient channels 8 (cc - 1) ..):
+    // 15 360 contiguous bytes = 15 DMA instructions of 1 KiB; wave w moves pieces w, w + 4, w + 8 and (w < 3) w + 12
     auto issue = [&](int bb, int cc, int buf) {
         bb = bb < n ? bb : n - 1;
-        const size_t off = ((size_t)bb * T::C + cc * T::CK) * T::GPLANE + wave * 256 + lane * 4;
+        const float* src = ((cc & 1) ? dy : x) + ((size_t)bb * T::C + (cc >> 1) * 16) * T::GPLANE + wave * 256 + lane * 4;
         const unsigned l0 = lds_base + buf * (T::RAWBUF_FLOATS * 4) + wave * 1024;
-        wgw_dma16(x + off, l0);
-        wgw_dma16(dy + off, l0 + T::RAW_FLOATS * 4);
-        if (wave < 3 || lane < 32) {
-            wgw_dma16(x + off + 1024, l0 + 4096);
-            wgw_dma16(dy + off + 1024, l0 + T::RAW_FLOATS * 4 + 4096);
-        }
+        wgw_dma16(src, l0);
+        wgw_dma16(src + 1024, l0 + 4096);
+        wgw_dma16(src + 2048, l0 + 8192);
+        if (wave < 3) wgw_dma16(src + 3072, l0 + 12288);
+    };
+    // The DMA of chunk g+1 is requested one chunk ahead (two LDS buffers), which covers an L2 hit but not an HBM miss,
+    // and in a training step every chunk is a first touch for the XCD (its twelve sharers ask at the same moment).  So
+    // the 120 lines of chunk g + TOUCH_AHEAD are touched ahead of time: one 4-byte LDS-DMA per line, 30 lines per wave.
+    // Loads retire in order: the `vmcnt(1)` at the top of a chunk leaves the youngest request -- the touch -- in flight.
+    auto touch = [&](int bb, int cc) {
+        bb += (cc >> 4) * slices;
+        cc &= 15;
+        bb = bb < n ? bb : n - 1;
+        const float* src = ((cc & 1) ? dy : x) + ((size_t)bb * T::C + (cc >> 1) * 16) * T::GPLANE + (wave * 30 + lane) * 32;
+        if (lane < 30 && APZ_WGW_TOUCH) wgw_touch(src, lds_base + (2 * T::RAWBUF_FLOATS + 2 * T::OP_FLOATS) * 4);
     };
     issue(slice, 0, 0);
+#pragma unroll
+    for (int d = 1; d < T::TOUCH_AHEAD; d++) touch(slice, d);
 
     for (int b = slice; b < n; b += slices) {
 #pragma unroll 2
         for (int c = 0; c < T::NCHUNK; c++) {
             const int buf = c & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c have landed ...
+            if (APZ_WGW_TOUCH)
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // this wave's pieces of chunk c have landed ...
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                    // ... everybody's have, and chunk c-1 (and the MFMA phase) is consumed
             if (c + 1 < T::NCHUNK)
                 issue(b, c + 1, buf ^ 1);            // the next chunk of this board ...
             else
                 issue(b + slices, 0, buf ^ 1);       // ... or the first chunk of this workgroup's next board
+            touch(b, c + T::TOUCH_AHEAD);
             // ---- transform this chunk's units to the workgroup's three positions.  Operand rows are swizzled: channel
             // ch of tile t sits at slot (ch & 15) ^ 2 (t >> 1) of its 16-channel group, which spreads the 32 lanes of a
             // write (2 channels x 16 tiles; tiles are 16 banks apart) over 32 banks and permutes only within the 16
             // channels that one MFMA operand read takes
             const float* rb = raw + buf * T::RAWBUF_FLOATS;
-            const int wpos = ((c >> 1) * 16 + utile) * 16 + ((((c & 1) * 8) + uch) ^ (2 * (utile >> 1)));
-            if (is_x) {
+            const int wpos = ((c >> 1) * 16 + utile) * 16 + (uch ^ (2 * (utile >> 1)));
+            if ((c & 1) == 0) {
                 float r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // row i of B^T d, six columns
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-                    // columns 0..3 of the 6x6 patch are one 16-byte read; columns -1 and 4 are the neighbouring tiles'
-                    // columns 3 and 0, taken from the neighbouring lanes (as LDS reads they were 4-way bank-conflicted)
-                    const f32x4 c03 = *reinterpret_cast<const f32x4*>(rb + ro[a]);
+                // columns 0..3 of the 6x6 patch are one 16-byte read; columns -1 and 4 are the neighbouring tiles'
+                // columns 3 and 0, taken from the neighbouring lanes (as LDS reads they were 4-way bank-conflicted)
+                auto row = [&](const float cf, const int off) {
+                    const f32x4 c03 = *reinterpret_cast<const f32x4*>(rb + off);
                     const float cm1 = wgw_quad_neighbour<false>(c03[3], utx);
                     const float c4 = wgw_quad_neighbour<true>(c03[0], utx);
-                    r[0] = __builtin_fmaf(cf[a], cm1, r[0]);
-                    r[1] = __builtin_fmaf(cf[a], c03[0], r[1]);
-                    r[2] = __builtin_fmaf(cf[a], c03[1], r[2]);
-                    r[3] = __builtin_fmaf(cf[a], c03[2], r[3]);
-                    r[4] = __builtin_fmaf(cf[a], c03[3], r[4]);
-                    r[5] = __builtin_fmaf(cf[a], c4, r[5]);
-                }
+                    r[0] = __builtin_fmaf(cf, cm1, r[0]);
+                    r[1] = __builtin_fmaf(cf, c03[0], r[1]);
+                    r[2] = __builtin_fmaf(cf, c03[1], r[2]);
+                    r[3] = __builtin_fmaf(cf, c03[2], r[3]);
+                    r[4] = __builtin_fmaf(cf, c03[3], r[4]);
+                    r[5] = __builtin_fmaf(cf, c4, r[5]);
+                };
+                row(cx0, xo0);
+                row(cx1, xbase + 16);
+                row(cx2, xbase + 32);
+                row(cx3, xbase + 48);
+                row(cx4, xo4);
+                row(cx5, xo5);
 #pragma unroll
                 for (int kk = 0; kk < T::NPOS; kk++) {
                     float o = 0.f;
@@ -166,9 +194,11 @@ __device__ __forceinline__ void wgrad_wino_body(const float* __restrict__ x, con
                     opv[kk * 2048 + wpos] = o;
                 }
             } else {
-                f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};   // row i of A dY, four columns (one 16-byte read per tile row)
-#pragma unroll
-                for (int a = 0; a < 4; a++) r4 += cf[a] * *reinterpret_cast<const f32x4*>(rb + ro[a]);
+                // row i of A dY, four columns (one 16-byte read per tile row)
+                f32x4 r4 = cy0 * *reinterpret_cast<const f32x4*>(rb + ybase);
+                r4 += cy1 * *reinterpret_cast<const f32x4*>(rb + ybase + 16);
+                r4 += cy2 * *reinterpret_cast<const f32x4*>(rb + ybase + 32);
+                r4 += cy3 * *reinterpret_cast<const f32x4*>(rb + yo3);
                 const float r[4] = {r4[0], r4[1], r4[2], r4[3]};
 #pragma unroll
                 for (int kk = 0; kk < T::NPOS; kk++) {

@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // mode 0: plain 16-B stores, a wave writes 1 KiB contiguous; mode 1: the same, nontemporal;
 // mode 2: 960-B planes (60 lanes), nontemporal, 16 planes per wave burst (the stem's epilogue shape)
 template <int MODE>
-__global__ __launch_bounds__(256) void fill(float* out, size_t n16, float v) {
+__global__ __launch_bounds__(256) void fill(float* out, size_t n16, float v, int stride16 = 7680, int rot = 0) {
     const f32x4 val = {v, v, v, v};
     if (MODE < 2) {
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
@@ -48,6 +48,19 @@ __global__ __launch_bounds__(256) void fill(float* out, size_t n16, float v) {
                 for (int i = 0; i < 30; i++) base[(4 * i + wave) * 64 + lane] = val;
             }
         }
+    } else if (MODE == 9) {
+        // mode 5 (a workgroup streams its own board in 4 KiB steps) with the boards `stride16` 16-byte pieces apart
+        // and workgroup k starting its sweep `rot * k` steps into the board (wrapping)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const size_t boards = n16 / stride16;
+        for (size_t b = blockIdx.x; b < boards; b += gridDim.x) {
+            f32x4* base = reinterpret_cast<f32x4*>(out) + b * stride16;
+            const int start = (rot * (int)blockIdx.x) % 30;
+            for (int i = 0; i < 30; i++) {
+                const int ii = (i + start) % 30;
+                base[(4 * ii + wave) * 64 + lane] = val;
+            }
+        }
     } else if (MODE == 7 || MODE == 8) {
         // a workgroup writes 16 planes (15 KiB = one 16-channel tile of one board) per step, its four waves taking
         // planes 4 i + w.  mode 7: chunks dealt round-robin over the workgroups; mode 8: XCD x (workgroup id mod 8)
@@ -83,34 +96,40 @@ __global__ __launch_bounds__(256) void fill(float* out, size_t n16, float v) {
 }
 
 int main() {
-    const size_t bytes = (size_t)8192 * 128 * 960;     // the stem's output at 8192 boards
+    const size_t bytes = (size_t)8192 * 128 * 960 + (size_t)8192 * 4096 * 4;     // room for padded strides
     float* d;
     hipMalloc(&d, bytes);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    for (int grid : {256, 512, 1024}) {
-        for (int mode : {0, 6, 7, 8}) {
-            float best = 1e9, sum = 0;
-            for (int it = 0; it < 12; it++) {
-                hipEventRecord(a);
-                if (mode == 0) hipLaunchKernelGGL(fill<0>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 1) hipLaunchKernelGGL(fill<1>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 2) hipLaunchKernelGGL(fill<2>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 3) hipLaunchKernelGGL(fill<3>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 4) hipLaunchKernelGGL(fill<4>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 5) hipLaunchKernelGGL(fill<5>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 6) hipLaunchKernelGGL(fill<6>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 7) hipLaunchKernelGGL(fill<7>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                if (mode == 8) hipLaunchKernelGGL(fill<8>, dim3(grid), dim3(256), 0, 0, d, bytes / 16, 1.0f);
-                hipEventRecord(b);
-                hipEventSynchronize(b);
-                float ms;
-                hipEventElapsedTime(&ms, a, b);
-                if (it >= 2) { best = ms < best ? ms : best; sum += ms; }
+    auto run = [&](const char* label, auto launch) {
+        float best = 1e9, sum = 0;
+        for (int it = 0; it < 12; it++) {
+            hipEventRecord(a);
+            launch();
+            hipEventRecord(b);
+            hipEventSynchronize(b);
+            float ms;
+            hipEventElapsedTime(&ms, a, b);
+            if (it >= 2) { best = ms < best ? ms : best; sum += ms; }
+        }
+        const double gb = 8192.0 * 122880;
+        printf("%-44s best %.1f us (%.2f TB/s)  mean %.1f us (%.2f TB/s)\n", label, best * 1e3, gb / best / 1e9, sum / 10 * 1e3,
+               gb / (sum / 10) / 1e9);
+    };
+    const size_t n16 = (size_t)8192 * 7680;
+    for (int grid : {256, 512}) {
+        char lab[128];
+        snprintf(lab, sizeof lab, "grid %d mode 0 (1 MiB window)", grid);
+        run(lab, [&] { hipLaunchKernelGGL(fill<0>, dim3(grid), dim3(256), 0, 0, d, n16, 1.0f, 7680, 0); });
+        snprintf(lab, sizeof lab, "grid %d mode 6 (stem today)", grid);
+        run(lab, [&] { hipLaunchKernelGGL(fill<6>, dim3(grid), dim3(256), 0, 0, d, n16, 1.0f, 7680, 0); });
+        for (int stride_blocks : {30, 31, 32, 33}) {
+            for (int rot : {0, 1, 7}) {
+                const int stride16 = stride_blocks * 256;
+                snprintf(lab, sizeof lab, "grid %d mode 9 stride %d x 4 KiB rot %d", grid, stride_blocks, rot);
+                run(lab, [&] { hipLaunchKernelGGL(fill<9>, dim3(grid), dim3(256), 0, 0, d, (size_t)8192 * stride16, 1.0f, stride16, rot); });
             }
-            printf("grid %4d mode %d: best %.1f us (%.2f TB/s)  mean %.1f us (%.2f TB/s)\n", grid, mode, best * 1e3,
-                   bytes / best / 1e9, sum / 10 * 1e3, bytes / (sum / 10) / 1e9);
         }
     }
     return 0;
