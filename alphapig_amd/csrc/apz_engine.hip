@@ -1443,6 +1443,18 @@ int apz_adam_step(apz_engine* e, const void* table_host, int ntensors, float lr_
 
 // ---- heads and loss of the training graph (csrc/heads_train.h)
 namespace {
+// C[M][N] = A B (+ bias): 64 x 64 tiles per workgroup when those fill the chip, else 64 x 16
+void launch_sgemm(apz_engine* e, const float* a, const float* b, const float* bias, float* c, int M, int N, int K, long a_rs,
+                  long a_cs, long b_rs, long b_cs, int ldc) {
+    const int my = (M + 63) / 64;
+    if (((N + 63) / 64) * my >= e->num_cu / 2)
+        hipLaunchKernelGGL(apz::sgemm_mfma_kernel<4>, dim3((N + 63) / 64, my), dim3(256), 0, e->stream, a, b, bias, c, M, N, K, a_rs,
+                           a_cs, b_rs, b_cs, ldc);
+    else
+        hipLaunchKernelGGL(apz::sgemm_mfma_kernel<1>, dim3((N + 15) / 16, my), dim3(256), 0, e->stream, a, b, bias, c, M, N, K, a_rs,
+                           a_cs, b_rs, b_cs, ldc);
+}
+
 int head_scratch(apz_engine* e, size_t floats) {
     if (floats > e->head_scratch_floats) {
         if (e->head_scratch) HIP_TRY(hipFree(e->head_scratch));
@@ -1484,7 +1496,7 @@ int apz_conv1x1_bwd(apz_engine* e, const void* x_dev, const void* w_dev, const v
     hipLaunchKernelGGL(apz::conv1x1_bwd_kernel, dim3(n), dim3(256), lds, e->stream, (const float*)x_dev, (const float*)w_dev,
                        (const float*)dy_dev, (float*)dx_dev, e->head_scratch, C, CO, e->cfg.height, e->cfg.width, ps, rs,
                        accumulate_dx);
-    hipLaunchKernelGGL(apz::colsum_kernel, dim3((CO * C + 255) / 256), dim3(256), 0, e->stream, (const float*)e->head_scratch,
+    hipLaunchKernelGGL(apz::colsum_kernel, dim3((CO * C + 63) / 64), dim3(256), 0, e->stream, (const float*)e->head_scratch,
                        (float*)dw_dev, n, CO * C, 1.0f);
     HIP_TRY(hipGetLastError());
     if (db_dev) return apz_bias_grad(e, dy_dev, db_dev, n, CO, APZ_LAYOUT_DENSE, stream);
@@ -1502,7 +1514,7 @@ int apz_bias_grad(apz_engine* e, const void* dy_dev, void* db_dev, int n, int C,
     if (int rc = head_scratch(e, (size_t)slices * C)) return rc;
     hipLaunchKernelGGL(apz::bias_grad_kernel, dim3(C, slices), dim3(256), 0, e->stream, (const float*)dy_dev, e->head_scratch, n, C,
                        ps);
-    hipLaunchKernelGGL(apz::colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, e->stream, (const float*)e->head_scratch,
+    hipLaunchKernelGGL(apz::colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, e->stream, (const float*)e->head_scratch,
                        (float*)db_dev, slices, C, 1.0f);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
@@ -1528,8 +1540,8 @@ int apz_fc_fwd(apz_engine* e, const void* x_dev, const void* w_dev, const void* 
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     // y[n][N] = x[n][K] W[N][K]^T + b:  A = x (row stride K), B(k, j) = W[j][k]
-    hipLaunchKernelGGL(apz::sgemm_mfma_kernel, dim3((N + 63) / 64, (n + 63) / 64), dim3(256), 0, e->stream, (const float*)x_dev,
-                       (const float*)w_dev, (const float*)bias_dev, (float*)y_dev, n, N, K, (long)K, 1L, 1L, (long)K, N);
+    launch_sgemm(e, (const float*)x_dev, (const float*)w_dev, (const float*)bias_dev, (float*)y_dev, n, N, K, (long)K, 1L, 1L,
+                 (long)K, N);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -1541,15 +1553,11 @@ int apz_fc_bwd(apz_engine* e, const void* x_dev, const void* w_dev, const void* 
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
     if (dx_dev)     // dx[n][K] = dy[n][N] W[N][K]
-        hipLaunchKernelGGL(apz::sgemm_mfma_kernel, dim3((K + 63) / 64, (n + 63) / 64), dim3(256), 0, e->stream,
-                           (const float*)dy_dev, (const float*)w_dev, (const float*)nullptr, (float*)dx_dev, n, K, N, (long)N, 1L,
-                           (long)K, 1L, K);
+        launch_sgemm(e, (const float*)dy_dev, (const float*)w_dev, nullptr, (float*)dx_dev, n, K, N, (long)N, 1L, (long)K, 1L, K);
     if (dw_dev)     // dW[N][K] = dy^T[N][n] x[n][K]:  A(m, k) = dy[k][m]
-        hipLaunchKernelGGL(apz::sgemm_mfma_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, e->stream,
-                           (const float*)dy_dev, (const float*)x_dev, (const float*)nullptr, (float*)dw_dev, N, K, n, 1L, (long)N,
-                           (long)K, 1L, K);
+        launch_sgemm(e, (const float*)dy_dev, (const float*)x_dev, nullptr, (float*)dw_dev, N, K, n, 1L, (long)N, (long)K, 1L, K);
     if (db_dev)
-        hipLaunchKernelGGL(apz::colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, e->stream, (const float*)dy_dev, (float*)db_dev,
+        hipLaunchKernelGGL(apz::colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, e->stream, (const float*)dy_dev, (float*)db_dev,
                            n, N, 1.0f);
     HIP_TRY(hipGetLastError());
     return APZ_OK;

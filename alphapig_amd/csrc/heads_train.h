@@ -98,15 +98,30 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const float* __restric
     }
 }
 
-// out[j] = sum_i in[i][j] over `rows` rows of `cols` floats, rows summed in index order (deterministic);
-// used for dw of the 1x1 convolutions (rows = boards), bias gradients (rows = batch) and the loss terms.
+// out[j] = scale * sum_i in[i][j] over `rows` rows of `cols` floats, in a fixed order (deterministic): a workgroup owns
+// 64 columns, wave w the rows w, w + 4, ...; eight loads are in flight per lane and the four partial sums meet in
+// LDS in wave order.  (One thread per column walking the rows one dependent load at a time took 20 us for a few KB.)
+// Used for dw of the 1x1 convolutions (rows = boards), bias gradients (rows = batch or batch slices) and the loss terms.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
                                                      float scale) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
     double s = 0.0;
-    for (int i = 0; i < rows; i++) s += (double)in[(size_t)i * cols + j];
-    out[j] = (float)(s * (double)scale);
+    if (j < cols) {
+        int i = wave;
+        for (; i + 28 < rows; i += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = in[(size_t)(i + 4 * u) * cols + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += (double)v[u];
+        }
+        for (; i < rows; i += 4) s += (double)in[(size_t)i * cols + j];
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < cols) out[j] = (float)((((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) * (double)scale);
 }
 
 // part[s][c] = sum over the boards of slice s and the cells of plane c of dy[n][c][.] (planes of `ps` floats: dense, or
@@ -147,21 +162,24 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y,
 // A workgroup (4 waves) owns a 64 x 64 tile of C; wave w its rows 16w..16w+15, four 16 x 16 MFMA tiles wide.
 // The matrices here are small (<= 512 x 900 x 900: 0.2-0.8 GFLOP per product), operands are read straight from
 // global memory / L2 per k-step.
+// NT = 16-column tiles per wave (workgroup tile 64 x 16 NT): 4 for big outputs, 1 when 64 x 64 tiles would leave most
+// CUs idle (the layers here are 512 x 225 x 900: 32 workgroups of 64 x 64).
+template <int NT>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ bias, float* __restrict__ c, int M, int N,
                                                          int K, long a_rs, long a_cs, long b_rs, long b_cs, int ldc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * (16 * NT);
     const int r = lane & 15, kq = lane >> 4;
-    f32x4 acc[4];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool mrow = m0 + r < M;
     for (int k0 = 0; k0 < K; k0 += 4) {
         const int k = k0 + kq;
         const float av = (mrow && k < K) ? a[(long)(m0 + r) * a_rs + (long)k * a_cs] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < NT; t++) {
             const int nn = n0 + t * 16 + r;
             const float bv = (nn < N && k < K) ? b[(long)k * b_rs + (long)nn * b_cs] : 0.f;
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
     }
     // D layout: column = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < NT; t++) {
         const int nn = n0 + t * 16 + r;
         if (nn >= N) continue;
         const float bb = bias ? bias[nn] : 0.f;
