@@ -405,7 +405,8 @@ int launch_stem15_t(apz_engine* e, const ConvLayer& L, const float* in, float* o
                                     lds));
         configured = true;
     }
-    const int grid = std::min(n, e->num_cu * 2);   // two resident workgroups per CU
+    // two resident workgroups per CU; at C_in = 4 twice as many workgroups as fit, so that the dispatcher evens out the tail
+    const int grid = std::min(n, e->num_cu * (C4 == 1 ? 4 : 2));
     hipLaunchKernelGGL((apz::stem15_kernel<C4, CIN, CODES>), dim3(grid), dim3(256), lds, e->stream, in, L.wpk, L.bias, out, n,
                        L.cin, (int)e->code_stride);
     HIP_TRY(hipGetLastError());

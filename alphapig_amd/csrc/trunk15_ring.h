@@ -224,14 +224,33 @@ namespace apz {
 //     are built straight into the LDS tile -- the separate encode kernel, its 4 MB of planes and a launch disappear
 //     from the forward.
 // wpk: [8][C4][9][64]; out: rows16 [n][128][15][16].
+// C4 == 1 (the HBM-bound shape): a wave accumulates ONE of its two 16-channel tiles at a time, so the first tile's
+// stores are in flight while the second tile's MFMAs run (within the wave, on top of the overlap between the two
+// resident workgroups).  Measured with tools/stem_bench.hip at 8192 boards (mean of 10 launches): both tiles at once
+// 214-218 us, one at a time 198-205 us; staging 8 instead of 16 channels per store burst (which would fit a third
+// workgroup per CU) 227-254 us -- shorter bursts cost more than the extra workgroup gives; grids that do not divide
+// the batch (768) lose 20 % to the tail.
+#ifndef APZ_STEM_OCC        // experiment switches of tools/stem_bench.hip (workgroups per CU, channels staged at a time,
+#define APZ_STEM_OCC 2     // channel tiles accumulated at a time) for the C_in = 4 shape
+#endif
+#ifndef APZ_STEM_SCH
+#define APZ_STEM_SCH 16
+#endif
+#ifndef APZ_STEM_CTB
+#define APZ_STEM_CTB 1
+#endif
+#ifndef APZ_STEM_CTB9      // the same for the C_in = 9 shape
+#define APZ_STEM_CTB9 1
+#endif
 template <int C4, int CIN, bool CODES = false>
-__global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+__global__ __launch_bounds__(256, (C4 == 1 ? APZ_STEM_OCC : 2)) void stem15_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int n, int cin, int code_stride = 0) {
     using T = Trunk15;
     constexpr int NPL = 4 * C4;
     constexpr int LDSF = T::FRONT + NPL * T::LPS + 32;
     constexpr int OST = 244;                       // staged output row stride: 16 lanes x 16 B hit 64 distinct banks
+    constexpr int SCH = (C4 == 1) ? APZ_STEM_SCH : 16;   // channels staged at a time
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [LDSF tile][4 waves x 16 x OST staging]
     float* tile = lds + T::FRONT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
     const int lane_off = q * T::LPS + j - 17;
     const int total = cin * 225;
     constexpr int NPF = (CIN * 225 + 255) / 256;   // input floats per thread per board (4 or 8)
-    constexpr bool PREFETCH = (C4 == 1) || CODES;  // C_in = 9 planes: no registers to spare (256-VGPR cap); codes: two bytes
+    constexpr bool PREFETCH = true;                // (one tile at a time leaves the registers for it at C_in = 9 too)
     // The stores of board b must drain WHILE board b+1 computes.  vmcnt retires in order, so
     // the next board's planes are loaded into registers BEFORE this board's stores are issued
     // (their wait then never covers a store), and the barriers protecting the LDS tile are raw
@@ -320,67 +339,77 @@ __global__ __launch_bounds__(256, 2) void stem15_kernel(const float* __restrict_
         lds_barrier();
         if (PREFETCH) prefetch(b + gridDim.x);  // lands during the MFMAs below
 
-        f32x4 acc[2][15];
+        constexpr int CTB = (C4 == 1) ? APZ_STEM_CTB : APZ_STEM_CTB9;   // channel tiles accumulated at a time
+        float* st = lds + LDSF + wave * (SCH * OST);
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++)
+        for (int cb = 0; cb < 2; cb += CTB) {
+            f32x4 acc[CTB][15];
 #pragma unroll
-            for (int t = 0; t < 15; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < CTB; ct++)
 #pragma unroll
-        for (int c4 = 0; c4 < C4; c4++) {
-            const float* bptr = tile + lane_off + c4 * 4 * T::LPS;
+                for (int t = 0; t < 15; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                float r[17];
+            for (int c4 = 0; c4 < C4; c4++) {
+                const float* bptr = tile + lane_off + c4 * 4 * T::LPS;
 #pragma unroll
-                for (int f = 0; f < 17; f++) r[f] = bptr[f * 16 + kx];
+                for (int kx = 0; kx < 3; kx++) {
+                    float r[17];
 #pragma unroll
-                for (int ky = 0; ky < 3; ky++)
+                    for (int f = 0; f < 17; f++) r[f] = bptr[f * 16 + kx];
 #pragma unroll
-                    for (int t = 0; t < 15; t++)
+                    for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-                        for (int ct = 0; ct < 2; ct++)
-                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[t + ky], a[ct][c4][ky * 3 + kx],
-                                                                              acc[ct][t], 0, 0, 0);
+                        for (int t = 0; t < 15; t++)
+#pragma unroll
+                            for (int ct = 0; ct < CTB; ct++)
+                                acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[t + ky], a[cb + ct][c4][ky * 3 + kx],
+                                                                                  acc[ct][t], 0, 0, 0);
+                }
             }
-        }
-        lds_barrier();                        // every wave is done reading the tile
-        // ---- epilogue through LDS: the accumulator layout gives 64-B pieces per (channel, row);
-        // written straight to HBM that pattern tops out at ~4.2 TB/s.  Each wave transposes its
-        // 16-channel tile in a private LDS staging area and streams whole 960-B planes instead.
-        float* st = lds + LDSF + wave * (16 * OST);
+            if (cb + CTB == 2) lds_barrier();     // every wave is done reading the tile
+            // ---- epilogue through LDS: the accumulator layout gives 64-B pieces per (channel, row);
+            // written straight to HBM that pattern tops out at ~4.2 TB/s.  Each wave transposes its
+            // 16-channel tile in a private LDS staging area and streams whole 960-B planes instead.
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) {
+            for (int ctl = 0; ctl < CTB; ctl++) {
+                const int ct = cb + ctl;
 #pragma unroll
-            for (int t = 0; t < 15; t++) {
-                f32x4 v = acc[ct][t];
-                v[0] = fmaxf(v[0] + bv[ct], 0.f);
-                v[1] = fmaxf(v[1] + bv[ct], 0.f);
-                v[2] = fmaxf(v[2] + bv[ct], 0.f);
-                v[3] = (q == 3) ? 0.f : fmaxf(v[3] + bv[ct], 0.f);
-                *reinterpret_cast<f32x4*>(st + j * OST + t * 16 + q * 4) = v;
+                for (int half = 0; half < 16 / SCH; half++) {
+                    if (SCH == 16 || (j >> 3) == half) {
+#pragma unroll
+                        for (int t = 0; t < 15; t++) {
+                            f32x4 v = acc[ctl][t];
+                            v[0] = fmaxf(v[0] + bv[ct], 0.f);
+                            v[1] = fmaxf(v[1] + bv[ct], 0.f);
+                            v[2] = fmaxf(v[2] + bv[ct], 0.f);
+                            v[3] = (q == 3) ? 0.f : fmaxf(v[3] + bv[ct], 0.f);
+                            *reinterpret_cast<f32x4*>(st + (j & (SCH - 1)) * OST + t * 16 + q * 4) = v;
+                        }
+                    }
+                    // lanes exchange data through the wave-private staging area: keep the compiler from moving a
+                    // lane's reads above its own (different-address) writes, and the next tile's writes above these reads
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    float* dst = out + ((size_t)b * T::C + (wave * 2 + ct) * 16 + half * SCH) * T::GPLANE + lane * 4;
+                    if (lane < 60) {
+#pragma unroll
+                        for (int c = 0; c < SCH; c++)
+                            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(st + c * OST + lane * 4),
+                                                        reinterpret_cast<f32x4*>(dst + c * T::GPLANE));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
             }
-            // lanes exchange data through the wave-private staging area: keep the compiler from moving a
-            // lane's reads above its own (different-address) writes, and the next tile's writes above these reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float* dst = out + ((size_t)b * T::C + (wave * 2 + ct) * 16) * T::GPLANE + lane * 4;
-            if (lane < 60) {
-#pragma unroll
-                for (int c = 0; c < 16; c++)
-                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(st + c * OST + lane * 4),
-                                                reinterpret_cast<f32x4*>(dst + c * T::GPLANE));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
 
 template <int C4>
 constexpr int stem15_lds_bytes() {
-    return (Trunk15::FRONT + 4 * C4 * Trunk15::LPS + 32 + 4 * 16 * 244) * (int)sizeof(float);
+    return (Trunk15::FRONT + 4 * C4 * Trunk15::LPS + 32 + 4 * (C4 == 1 ? APZ_STEM_SCH : 16) * 244) * (int)sizeof(float);
 }
 
 }  // namespace apz
