@@ -270,6 +270,21 @@ __global__ __launch_bounds__(256, (C4 == 1 ? APZ_STEM_OCC : 2)) void stem15_kern
     float bv[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) bv[ct] = bias[(wave * 2 + ct) * 16 + j];
+    // C_in = 9: channels 0..7 are two full k-groups of four; the ninth channel alone would fill a third group to a
+    // quarter (9 of 27 k-steps multiplying zeros).  Its nine taps are contracted as k instead: three k-steps in which
+    // lane group q holds tap 4 s + q (taps 9..11: zero weight) -- 21 k-steps per output row instead of 27.
+    constexpr bool NINTH = (CIN == 9);
+    constexpr int NC4 = NINTH ? 2 : C4;            // k-groups walked tap by tap with the sliding row window
+    float a9[2][3];
+    int b9[3];
+#pragma unroll
+    for (int s9 = 0; s9 < 3; s9++) {
+        const int tap = 4 * s9 + q, tp = tap < 9 ? tap : 0;
+        b9[s9] = 8 * T::LPS + (tp / 3) * 16 + (tp % 3) + j - 17;
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+            a9[ct][s9] = (NINTH && tap < 9) ? wpk[((((size_t)(wave * 2 + ct)) * C4 + 2) * 9 + tp) * 64 + j] : 0.f;
+    }
 
     const int lane_off = q * T::LPS + j - 17;
     const int total = cin * 225;
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(256, (C4 == 1 ? APZ_STEM_OCC : 2)) void stem15_kern
 #pragma unroll
                 for (int t = 0; t < 15; t++) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c4 = 0; c4 < C4; c4++) {
+            for (int c4 = 0; c4 < NC4; c4++) {
                 const float* bptr = tile + lane_off + c4 * 4 * T::LPS;
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
@@ -364,6 +379,19 @@ __global__ __launch_bounds__(256, (C4 == 1 ? APZ_STEM_OCC : 2)) void stem15_kern
                             for (int ct = 0; ct < CTB; ct++)
                                 acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[t + ky], a[cb + ct][c4][ky * 3 + kx],
                                                                                   acc[ct][t], 0, 0, 0);
+                }
+            }
+            if (NINTH) {
+#pragma unroll
+                for (int s9 = 0; s9 < 3; s9++) {
+                    float r9[15];
+#pragma unroll
+                    for (int t = 0; t < 15; t++) r9[t] = tile[b9[s9] + t * 16];
+#pragma unroll
+                    for (int t = 0; t < 15; t++)
+#pragma unroll
+                        for (int ct = 0; ct < CTB; ct++)
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r9[t], a9[cb + ct][s9], acc[ct][t], 0, 0, 0);
                 }
             }
             if (cb + CTB == 2) lds_barrier();     // every wave is done reading the tile
