@@ -64,6 +64,10 @@ struct Wino3 {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+#ifndef APZ3_EARLY_BARRIER
+#define APZ3_EARLY_BARRIER 1
+#endif
+
 #ifdef APZ3_EPI_WAIT
 #define APZ3_FENCE()                                  \
     {                                                 \
@@ -315,6 +319,15 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #elif defined(APZ3_PRIO) && APZ3_PRIO == 2
     if (ph == 0) __builtin_amdgcn_s_setprio(1);
 #endif
+    f32x2 bc0, bc1;                                 // B operands of the current slot (both boards), carried across chunks
+#if APZ3_EARLY_BARRIER
+    __syncthreads();                                // V[0] (chunk 0) complete
+    {
+        const float* vp0 = vb + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+        bc0 = *reinterpret_cast<const f32x2*>(vp0);
+        bc1 = *reinterpret_cast<const f32x2*>(vp0 + 256);
+    }
+#endif
     for (int t = 0; t < nitems; t++) {
         const int h = item_half(t);
         const int bd0 = 2 * item_pair(t);
@@ -338,10 +351,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #endif
         auto chunk = [&](int g, auto PAR) {
             constexpr int par = decltype(PAR)::value;
+            const float* vp = vb + par * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+            // APZ3_EARLY_BARRIER: the chunk's barrier sits between slots 16 and 17 of the PREVIOUS chunk (see there) and
+            // bc0 / bc1 already hold this chunk's first operands.
+            const float* vpn = vb + (1 - par) * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+#if !APZ3_EARLY_BARRIER
             __syncthreads();                    // V[par] complete, V[1-par] and raw[par] free, raw[1-par] visible
             APZ3_STAMP(1)
-            const float* vp = vb + par * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
-            f32x2 bc0 = *reinterpret_cast<const f32x2*>(vp), bc1 = *reinterpret_cast<const f32x2*>(vp + 256);
+            bc0 = *reinterpret_cast<const f32x2*>(vp);
+            bc1 = *reinterpret_cast<const f32x2*>(vp + 256);
+#endif
 #define APZ3_SLOT(k)                                                                                               \
             {                                                                                                      \
                 constexpr int s = (k) / 9, m = (k) % 9, sn = ((k) + 1) / 9, mn = ((k) + 1) % 9;                        \
@@ -350,6 +369,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 if ((k) + 1 < 18) {                                                                                \
                     bn0 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + sn * 128);                            \
                     bn1 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + 256 + sn * 128);                      \
+                } else if (APZ3_EARLY_BARRIER) {          /* the next chunk's first operands (V[1-par], complete) */ \
+                    bn0 = *reinterpret_cast<const f32x2*>(vpn);                                                    \
+                    bn1 = *reinterpret_cast<const f32x2*>(vpn + 256);                                              \
                 }                                                                                                  \
                 const float a0 = ur[m >> 1][(2 * m) & 3], a1 = ur[m >> 1][(2 * m + 1) & 3];                        \
                 acc[0][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc0[0], acc[0][2 * m], 0, 0, 0);          \
@@ -362,6 +384,14 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 if ((m & 1) || m == 8) ur[m >> 1] = uload(2 * g + s + 1, m >> 1);                                  \
                 bc0 = bn0;                                                                                         \
                 bc1 = bn1;                                                                                         \
+                if (APZ3_EARLY_BARRIER && (k) == 16) {                                                             \
+                    /* The chunk barrier, one slot early: the transform's last V writes were in slice 16, the last    \
+                       reads of V[par] were this slot's operand prefetch, raw[1-par] was last read in slices 0-2.     \
+                       Slot 17 then fetches the next chunk's first operands while its own MFMAs run, instead of all  \
+                       eight waves waiting out an LDS round trip with an empty matrix pipe after every barrier. */   \
+                    __syncthreads();                                                                               \
+                    APZ3_STAMP(1)                                                                                  \
+                }                                                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
             }
             APZ3_ALL18(APZ3_SLOT)
@@ -524,6 +554,12 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
             }
         }
         APZ3_STAMP(6)
+#if APZ3_EARLY_BARRIER
+        // the next item's first barrier comes only after its slot 16, and its transform slices write V[1] (= X) from
+        // slot 10 on: every wave must have read its last X values before anybody goes on
+        __syncthreads();
+        APZ3_STAMP(4)
+#endif
     }
     };
     if ((wave >> 2) == 0)
