@@ -349,6 +349,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #else
 #define APZ3_SLOT_PRIO(k)
 #endif
+        // (APZ3_ABLATE_TRANSFORM: measurement build of tools/wino3_bench.hip -- staging and input transform of the chunk
+        // body removed, the MFMAs run over whatever the prologue left in V: what the body would cost if V came ready-made)
+#ifdef APZ3_ABLATE_TRANSFORM
+#define APZ3_BODY_STAGING(k)
+#else
+#define APZ3_BODY_STAGING(k)                                                                     \
+    if ((k) == 0) raw_store(par);                        /* raw(g+2) */                          \
+    if ((k) == 1) raw_fetch(g + 3);                                                              \
+    tslice(1 - par, std::integral_constant<int, (k)>{}); /* chunk g+1 */
+#endif
         auto chunk = [&](int g, auto PAR) {
             constexpr int par = decltype(PAR)::value;
             const float* vp = vb + par * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
@@ -378,9 +388,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 acc[1][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc1[0], acc[1][2 * m], 0, 0, 0);          \
                 acc[0][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc0[1], acc[0][2 * m + 1], 0, 0, 0);  \
                 acc[1][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc1[1], acc[1][2 * m + 1], 0, 0, 0);  \
-                if ((k) == 0) raw_store(par);             /* raw(g+2) */                                            \
-                if ((k) == 1) raw_fetch(g + 3);                                                                    \
-                tslice(1 - par, std::integral_constant<int, (k)>{});   /* chunk g+1 */                             \
+                APZ3_BODY_STAGING(k)                                                                               \
                 if ((m & 1) || m == 8) ur[m >> 1] = uload(2 * g + s + 1, m >> 1);                                  \
                 bc0 = bn0;                                                                                         \
                 bc1 = bn1;                                                                                         \
