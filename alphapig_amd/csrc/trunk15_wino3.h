@@ -68,6 +68,7 @@ struct Wino3 {
 #define APZ3_EARLY_BARRIER 1
 #endif
 
+
 #ifdef APZ3_EPI_WAIT
 #define APZ3_FENCE()                                  \
     {                                                 \
@@ -207,10 +208,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         const float* rp = rawb + par * T::RAW_FLOATS + tr_off;
         float* vp = vb + par * T::V_FLOATS + tv_off;
         auto load_row = [&](int i) {
-            xr[i][0] = f32x2{rp[i * T::RROW - 1], rp[i * T::RROW + 4]};
+#ifdef APZ3_ABLATE_TREADS             /* measurement build: no LDS reads in the transform */
+            xr[i][0] = f32x2{(float)i, 1.f};
+            xr[i][1] = f32x2{2.f, (float)lane};
+            xr[i][2] = f32x2{3.f, 4.f};
+#else
             const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
+            xr[i][0] = f32x2{rp[i * T::RROW - 1], rp[i * T::RROW + 4]};
             xr[i][1] = f32x2{c03[0], c03[1]};
             xr[i][2] = f32x2{c03[2], c03[3]};
+#endif
         };
         if constexpr (K == 0) {
             load_row(0);
@@ -262,12 +269,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 const float o5 = __builtin_fmaf(4.f, v1, __builtin_fmaf(-5.f, v3, v5));
                 // two scalar stores per position pair: ds_write2_b32 takes any two registers (a b64 store wants an
                 // aligned pair and costs a v_mov per value)
+#ifdef APZ3_ABLATE_TWRITES            /* measurement build: one LDS write instead of six per row */
+                vp[(ii * 3 + 0) * T::VPP] = ((o0 + o14[0]) + (o14[1] + o14[2])) + (o14[3] + o5);
+#else
                 vp[(ii * 3 + 0) * T::VPP] = o0;
                 vp[(ii * 3 + 0) * T::VPP + 1] = o14[0];
                 vp[(ii * 3 + 1) * T::VPP] = o14[1];
                 vp[(ii * 3 + 1) * T::VPP + 1] = o14[2];
                 vp[(ii * 3 + 2) * T::VPP] = o14[3];
                 vp[(ii * 3 + 2) * T::VPP + 1] = o5;
+#endif
             }
         }
     };
@@ -354,10 +365,18 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #ifdef APZ3_ABLATE_TRANSFORM
 #define APZ3_BODY_STAGING(k)
 #else
+#if defined(APZ3_ABLATE_STAGING)      /* no global -> LDS staging of the raw planes (the transform reads stale tiles) */
+#define APZ3_BODY_STAGING(k) tslice(1 - par, std::integral_constant<int, (k)>{});
+#elif defined(APZ3_ABLATE_TSLICE)     /* staging only, no transform */
+#define APZ3_BODY_STAGING(k)                                                                     \
+    if ((k) == 0) raw_store(par);                                                                \
+    if ((k) == 1) raw_fetch(g + 3);
+#else
 #define APZ3_BODY_STAGING(k)                                                                     \
     if ((k) == 0) raw_store(par);                        /* raw(g+2) */                          \
     if ((k) == 1) raw_fetch(g + 3);                                                              \
     tslice(1 - par, std::integral_constant<int, (k)>{}); /* chunk g+1 */
+#endif
 #endif
         auto chunk = [&](int g, auto PAR) {
             constexpr int par = decltype(PAR)::value;
