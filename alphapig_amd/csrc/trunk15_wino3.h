@@ -67,6 +67,9 @@ struct Wino3 {
 #ifndef APZ3_EARLY_BARRIER
 #define APZ3_EARLY_BARRIER 1
 #endif
+#ifndef APZ3_EARLY_RESID
+#define APZ3_EARLY_RESID 1
+#endif
 
 
 #ifdef APZ3_EPI_WAIT
@@ -506,10 +509,12 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 // Residual planes: steps 0 and 1 only now -- at the top of the epilogue all 144 accumulators are live
                 // and registers in flight would spill -- steps 2, 3 one step ahead.  Always BEFORE the step's stores:
                 // vmcnt counts in issue order, so the wait for these loads leaves the stores in flight.
+#if !APZ3_EARLY_RESID
                 if (RESID && r == 0) {
                     resid_load(0);
                     resid_load(1);
                 }
+#endif
                 if (RESID && r >= 1 && r + 1 < 4) resid_load(r + 1);
                 f32x4 (&win)[4] = winb[r & 1];
                 APZ3_STAMP(3)
@@ -565,6 +570,26 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 for (int qp = 0; qp < 4; qp++)
                     bstore(r_out, st_out_vo, plane_so(r, qp), pv[qp]);
             };
+#if APZ3_EARLY_RESID
+            {
+                // Both partials of the OTHER board first: its 72 accumulators die, and the registers they free take the
+                // residual planes of steps 0 and 1 -- requested here, a transform pass ahead of their use, instead of
+                // inside step 0 where the epilogue then waited out their latency.
+                f32x2 qsa[3][4], qsb[3][4], qo[3][4];
+                partial2(acc[1 - own], std::integral_constant<int, 0>{}, qsa);
+                partial2(acc[1 - own], std::integral_constant<int, 2>{}, qsb);
+                if (RESID) {
+                    resid_load(0);
+                    resid_load(1);
+                }
+                partial2(acc[own], std::integral_constant<int, 0>{}, qo);
+                step(0, 0, qsa, qo);
+                step(1, 1, qsa, qo);
+                partial2(acc[own], std::integral_constant<int, 2>{}, qo);
+                step(2, 0, qsb, qo);
+                step(3, 1, qsb, qo);
+            }
+#else
             {
                 f32x2 qs[3][4], qo[3][4];
                 partial2(acc[1 - own], std::integral_constant<int, 0>{}, qs);
@@ -579,6 +604,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 step(2, 0, qs, qo);
                 step(3, 1, qs, qo);
             }
+#endif
         }
         APZ3_STAMP(6)
 #if APZ3_EARLY_BARRIER
