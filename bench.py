@@ -149,9 +149,21 @@ def spawn_ranks(n, argv):
     never does), pass rank 0's JSON line through, fail if any rank fails."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # a port BELOW the kernel's ephemeral range (32768+): a port number the kernel handed out for bind(0) may be
+    # taken by an outgoing connection of one of the ranks before rank 0 listens on it
+    import random
+    port = None
+    for _ in range(64):
+        cand = random.randint(20000, 32000)
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", cand))
+            except OSError:
+                continue
+        port = cand
+        break
+    if port is None:
+        raise SystemExit("bench.py: no free rendezvous port in 20000..32000")
     import tempfile
     procs = []
     out0 = tempfile.TemporaryFile()

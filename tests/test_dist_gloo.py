@@ -108,7 +108,7 @@ def test_eight_rank_rehearsal(tmp_path):
     up with the same gathered tuples, rank-major."""
     here = os.path.dirname(os.path.abspath(__file__))
     total, world = 19, 8
-    port = 33500 + random.randint(0, 2000)
+    port = 25500 + random.randint(0, 2000)
     env = dict(os.environ)
     env["OMP_NUM_THREADS"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
