@@ -298,6 +298,14 @@ int launch_conv_t(apz_engine* e, const ConvLayer& L, const float* in, const floa
     // the stem of the ring path hands its output to trunk15_ring.h in rows16 layout
     const bool to16 = e->ring && &L == &e->convs[0];
     const int ps = to16 ? e->act_ps : H * W, rs = to16 ? e->act_rs : W;
+    // Small batches (BASELINE config 2: 64 concurrent games = 32 boards per launch): one workgroup per board leaves most
+    // CUs idle and every workgroup streams the layer's whole weight set (2.4 MB at 256 x 256) through one CU's L2 port.
+    // Then each board goes to CT workgroups of 64 output channels (gridDim.y): same arithmetic per output element, in
+    // the same order -- only which wave owns which channel tile changes.
+    if (CT > 1 && n * CT <= 2 * e->num_cu) {
+        if (resid) return launch_conv_r<H, W, 1, true>(e, L, in, resid, out, n, ps, rs, 1, CT);
+        return launch_conv_r<H, W, 1, false>(e, L, in, resid, out, n, ps, rs, 1, CT);
+    }
     if (resid) return launch_conv_r<H, W, CT, true>(e, L, in, resid, out, n, ps, rs);
     return launch_conv_r<H, W, CT, false>(e, L, in, resid, out, n, ps, rs);
 }
