@@ -17,33 +17,50 @@
 namespace apz {
 
 // w6 [6][C] (rows 0-3 policy, 4-5 value, BN folded), b6 [6]
+// Thread = (pixel p, channel slice qq of Q): boards of at most 128 pixels (8x8) would leave most of the 256 threads idle
+// behind one serial chain of C dependent loads per pixel (64 us per 32 boards at C = 256), so the channels are dealt
+// round-robin over Q = 256 / HW (1, 2 or 4) slices and the slices' partial sums meet in LDS, added in slice order:
+// a board's bits do not depend on the batch or on the grid.
 __global__ __launch_bounds__(256) void head_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w6,
                                                            const float* __restrict__ b6, float* __restrict__ featp,
                                                            float* __restrict__ featv, int n, int C, int HW, int W, int in_ps,
                                                            int in_rs) {
     // input plane stride in_ps / row stride in_rs: dense NCHW (HW / W) or rows16 (240 / 16)
+    __shared__ float part[3 * 6 * 128];                   // slices 1..3: [slice - 1][output 6][pixel]
+    const int Q = HW <= 64 ? 4 : HW <= 128 ? 2 : 1;
+    const int tid = threadIdx.x;
+    const int qq = Q > 1 ? tid / HW : 0, pq = Q > 1 ? tid - qq * HW : tid;
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         const float* xb = x + (size_t)b * C * in_ps;
-        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
-            const int pin = (p / W) * in_rs + (p % W);
-            for (int c = 0; c < C; c++) {
-                const float v = xb[c * in_ps + pin];
-                a0 = fmaf(w6[0 * C + c], v, a0);
-                a1 = fmaf(w6[1 * C + c], v, a1);
-                a2 = fmaf(w6[2 * C + c], v, a2);
-                a3 = fmaf(w6[3 * C + c], v, a3);
-                a4 = fmaf(w6[4 * C + c], v, a4);
-                a5 = fmaf(w6[5 * C + c], v, a5);
+        for (int p0 = 0; p0 < HW; p0 += (Q > 1 ? HW : (int)blockDim.x)) {
+            const int p = p0 + pq;
+            const bool live = p < HW && qq < Q;
+            float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                const int pin = (p / W) * in_rs + (p % W);
+#pragma unroll 4
+                for (int c = qq; c < C; c += Q) {
+                    const float v = xb[c * in_ps + pin];
+#pragma unroll
+                    for (int o = 0; o < 6; o++) a[o] = fmaf(w6[o * C + c], v, a[o]);
+                }
+                if (qq > 0)
+#pragma unroll
+                    for (int o = 0; o < 6; o++) part[((qq - 1) * 6 + o) * 128 + p] = a[o];
             }
-            float* fp = featp + (size_t)b * 4 * HW;
-            float* fv = featv + (size_t)b * 2 * HW;
-            fp[0 * HW + p] = fmaxf(a0 + b6[0], 0.f);
-            fp[1 * HW + p] = fmaxf(a1 + b6[1], 0.f);
-            fp[2 * HW + p] = fmaxf(a2 + b6[2], 0.f);
-            fp[3 * HW + p] = fmaxf(a3 + b6[3], 0.f);
-            fv[0 * HW + p] = fmaxf(a4 + b6[4], 0.f);
-            fv[1 * HW + p] = fmaxf(a5 + b6[5], 0.f);
+            if (Q > 1) __syncthreads();
+            if (live && qq == 0) {
+                for (int s = 1; s < Q; s++)
+#pragma unroll
+                    for (int o = 0; o < 6; o++) a[o] += part[((s - 1) * 6 + o) * 128 + p];
+                float* fp = featp + (size_t)b * 4 * HW;
+                float* fv = featv + (size_t)b * 2 * HW;
+#pragma unroll
+                for (int o = 0; o < 4; o++) fp[o * HW + p] = fmaxf(a[o] + b6[o], 0.f);
+                fv[0 * HW + p] = fmaxf(a[4] + b6[4], 0.f);
+                fv[1 * HW + p] = fmaxf(a[5] + b6[5], 0.f);
+            }
+            if (Q > 1) __syncthreads();                   // `part` is reused by the next board
         }
     }
 }
