@@ -362,3 +362,22 @@ def test_trunk_kernels_agree_on_a_large_ragged_batch():
             np.testing.assert_array_equal(v2, outs[kind][1][perm])
         finally:
             net.close()
+
+
+def test_small_batch_channel_groups_do_not_change_a_boards_bits():
+    """The generic 3x3 convolution gives every board of a small batch to several workgroups of 64 output channels
+    (launch_conv_t, BASELINE config 2's 32-board launches) and one workgroup per board in large batches; the 1x1 head
+    convolution adds channel-slice partial sums in a fixed order.  Same boards, both launch shapes: identical bits
+    (policy_value_net_mxnet_simple.py:68-92 evaluated through policy_value, :232-242)."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("simple", 8, 8, 9, seed=6, style="bench")
+    net = PolicyValueNet(8, 8, batch_size=1024, model_params=prm, net_kind="simple")
+    _, planes = random_positions(1024, 8, seed=21)
+    big = net.forward_with_logits(planes)                       # 1024 x 4 channel groups > 2 x CUs: one workgroup per board
+    for lo, n in ((0, 32), (100, 7), (512, 64)):
+        small = net.forward_with_logits(planes[lo:lo + n])      # grouped launch
+        for a, b in zip(small, big):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b)[lo:lo + n])
+    o = net_ref.forward(prm, planes[:48], "simple", dtype=np.float64)
+    np.testing.assert_allclose(big[0][:48], o[0], rtol=0, atol=LOGIT_ATOL)
+    net.close()
