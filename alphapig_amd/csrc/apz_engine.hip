@@ -384,7 +384,7 @@ int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const
                                     hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         configured = true;
     }
-    const int grid = std::min((n + 1) / 2, e->num_cu);   // one persistent workgroup per CU; item = board pair x channel half
+    const int grid = apz::wino3_grid(n, e->num_cu);      // persistent workgroups; item = board pair x channel half
     if (resid)
         hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
                            L.bias, resid, out, n);
@@ -1211,10 +1211,10 @@ int apz_wino_conv_add(apz_engine* e, const void* x_dev, const void* upk_dev, con
                            e->wino_scratch[0], planes);
     const float* b = bias_dev ? (const float*)bias_dev : e->zeros256;
     const float* rs = (const float*)resid_dev;
-    const int grid = std::min((n + 1) / 2, e->num_cu);
     // the self-play path's kernel (csrc/trunk15_wino3.h); it addresses activations through 32-bit buffer offsets, so
     // batches of >= 2^31 / (128 * 960) boards take its predecessor
     const bool k3 = (long long)n * 128 * 960 < (1ll << 31);
+    const int grid = k3 ? apz::wino3_grid(n, e->num_cu) : std::min((n + 1) / 2, e->num_cu);
 #define APZ_WINO_TRAIN(KERNEL, LDS, SLOT, RESID, RELU)                                                                       \
     do {                                                                                                                     \
         bool& configured = e->lds_attr_set[SLOT];                                                                            \

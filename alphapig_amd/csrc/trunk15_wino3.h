@@ -626,4 +626,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #endif
 }
 
+// Launch grid for n boards on `num_cu` CUs.  At least as many board pairs as CUs: one workgroup per CU (duo mode when
+// num_cu is a multiple of 16, every workgroup takes >= 1 pair x one channel half).  Fewer pairs (training at the
+// reference's batch_size 128, small inference batches): TWO workgroups per pair -- the channel halves of a pair run on
+// two CUs at once instead of one after the other on one -- rounded up to whole groups of 16 blocks, which is what makes
+// the kernel pair blocks b and b + 8 up (duos beyond the last pair have no work and return).
+inline int wino3_grid(int n, int num_cu) {
+    const int npairs = (n + 1) >> 1;
+    if (npairs >= num_cu) return num_cu;
+    const int g = (2 * npairs + 15) & ~15;
+    return g <= num_cu ? g : num_cu;
+}
+
 }  // namespace apz

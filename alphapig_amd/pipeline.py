@@ -17,7 +17,6 @@ were built under the previous weights -- like the reference's, whose tree is als
 the update that happens between two games only at game boundaries; here the switch can fall
 inside a game).
 """
-import collections
 import logging
 import os
 import random
@@ -35,6 +34,47 @@ from .train import policy_update
 _logger = logging.getLogger(__name__)
 
 
+class ReplayBuffer(object):
+    """The reference's `deque(maxlen=buffer_size)` of (state, pi, z) tuples (train_mxnet.py:59) with O(1) random access:
+    `random.sample` on the deque costs O(buffer) per mini-batch (the reference's buffer holds 2 198 800 entries), a list
+    used as a ring does not.  Index 0 is the oldest entry, as in the deque."""
+
+    def __init__(self, maxlen):
+        self.maxlen = int(maxlen)
+        self._items = []
+        self._head = 0                   # position of the oldest entry once the ring is full
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, i):
+        n = len(self._items)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        return self._items[(self._head + i) % n] if n == self.maxlen else self._items[i]
+
+    def append(self, x):
+        if len(self._items) < self.maxlen:
+            self._items.append(x)
+        else:
+            self._items[self._head] = x
+            self._head = (self._head + 1) % self.maxlen
+
+    def extend(self, xs):
+        for x in xs:
+            self.append(x)
+
+    def __iter__(self):
+        for i in range(len(self._items)):
+            yield self[i]
+
+    def sample(self, rng, k):
+        """`rng.sample(list(buffer), k)` -- the same draws from the same generator state -- without the copy."""
+        return [self[j] for j in rng.sample(range(len(self._items)), k)]
+
+
 class TrainPipeline(object):
     def __init__(self, conf, init_model=None, policy_value_net=None, device=0, seed=0):
         self.board_width, self.board_height = conf["board_width"], conf["board_height"]
@@ -42,7 +82,7 @@ class TrainPipeline(object):
         self.learn_rate, self.lr_multiplier = conf["learn_rate"], conf.get("lr_multiplier", 1.0)
         self.temp, self.n_playout, self.c_puct = conf["temp"], conf["n_playout"], conf["c_puct"]
         self.batch_size = conf["batch_size"]
-        self.data_buffer = collections.deque(maxlen=conf["buffer_size"])
+        self.data_buffer = ReplayBuffer(conf["buffer_size"])
         self.play_batch_size = conf.get("play_batch_size", 1)
         self.epochs, self.kl_targ = conf["epochs"], conf["kl_targ"]
         self.check_freq, self.game_batch_num = conf["check_freq"], conf["game_batch_num"]
@@ -98,7 +138,7 @@ class TrainPipeline(object):
     # ---- update / evaluation ---------------------------------------------------------------
     def policy_update(self):
         """train_mxnet.py:194-240."""
-        mini = self._rng.sample(list(self.data_buffer), self.batch_size)
+        mini = self.data_buffer.sample(self._rng, self.batch_size)
         net = self.policy_value_net
         from .train import HipTrainer
         if getattr(net, "_trainer", None) is None:

@@ -95,3 +95,21 @@ def test_product_trainer_has_no_cpu_path():
     prm, _, _, _ = tiny_problem()
     with pytest.raises(RuntimeError):
         HipTrainer(prm, "resnet", n_blocks=1, batch_size=6)
+
+
+def test_replay_buffer_is_the_reference_deque_with_random_access():
+    """train_mxnet.py:59 / :196: deque(maxlen) + random.sample.  Same contents, order and sampled mini-batches."""
+    import collections
+    import random
+    from alphapig_amd.pipeline import ReplayBuffer
+    buf, dq = ReplayBuffer(37), collections.deque(maxlen=37)
+    for step in range(9):
+        chunk = [(step, k) for k in range(step * 3 + 1)]
+        buf.extend(chunk)
+        dq.extend(chunk)
+        assert len(buf) == len(dq) and list(buf) == list(dq) and buf[0] == dq[0] and buf[-1] == dq[-1]
+        if len(dq) >= 5:
+            a, b = random.Random(step), random.Random(step)
+            assert buf.sample(a, 5) == b.sample(list(dq), 5) and a.random() == b.random()
+    with pytest.raises(IndexError):
+        buf[37]

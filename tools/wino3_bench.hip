@@ -94,16 +94,17 @@ int main(int argc, char** argv) {
     const int check_sizes[7] = {1, 7, 64, 96, 512, 515, 1030};
     for (int ci = 0; ci < (getenv("APZ_NO_TIMING") ? 2 : 7); ci++) {
         const int n = check_sizes[ci];
-        const int grid = (n + 1) / 2 < 256 ? (n + 1) / 2 : 256;
+        const int grid = (n + 1) / 2 < 256 ? (n + 1) / 2 : 256;   // wino2: one workgroup per pair
+        const int grid3 = apz::wino3_grid(n, 256);
         for (int resid = 0; resid < 2; resid++) {
             CK(hipMemset(out, 0xff, (size_t)n * 128 * 240 * 4));
             CK(hipMemset(out2, 0xff, (size_t)n * 128 * 240 * 4));
             if (resid) {
                 hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out2, n);
-                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
             } else {
                 hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out2, n);
-                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
             }
             CK(hipDeviceSynchronize());
 #ifdef APZ3_DEBUG_X
@@ -186,11 +187,12 @@ int main(int argc, char** argv) {
 
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const int sizes[3] = {512, 1024, 4096};
+    const int sizes[4] = {128, 512, 1024, 4096};
     for (int rep = 0; rep < (getenv("APZ_NO_TIMING") ? 0 : 2); rep++)
-    for (int si = 0; si < 3; si++) {
+    for (int si = 0; si < 4; si++) {
         const int n = sizes[si];
-        const int grid = (n + 1) / 2 < 256 ? (n + 1) / 2 : 256;
+        const int grid = (n + 1) / 2 < 256 ? (n + 1) / 2 : 256;   // wino2: one workgroup per pair
+        const int grid3 = apz::wino3_grid(n, 256);
         for (int kern = 0; kern < 2; kern++)
         for (int resid = 0; resid < 2; resid++) {
             auto launch = [&]() {
@@ -198,8 +200,8 @@ int main(int argc, char** argv) {
                     if (resid) hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out, n);
                     else hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out, n);
                 } else {
-                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
-                    else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                    else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
                 }
             };
             for (int i = 0; i < 5; i++) launch();
@@ -217,8 +219,8 @@ int main(int argc, char** argv) {
     }
 #ifdef APZ_WINO3_STAMPS
     {
-        const int n = 512, grid = 256;
-        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+        const int n = 512, grid3 = 256;
+        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
         CK(hipDeviceSynchronize());
         unsigned long long hst[4 * 8 * 8];
         CK(hipMemcpyFromSymbol(hst, HIP_SYMBOL(apz::apz_wino3_stamps), sizeof(hst)));
