@@ -1,3 +1,9 @@
+// EXPERIMENT, not part of the product build: a fork of alphapig_amd/csrc/trunk15_wino3.h (round 2) in which one launch runs
+// all trunk layers of a forward (`trunk15_wino3_chain_kernel`, see the CHAIN paragraph below).  Measured bit-exact and NOT
+// faster than one launch per layer (profiles/r02_chain_*.log); kept with its harness
+// tools/wino3_chain_bench.hip so that the measurement can be repeated.  The fork also carries the register diet that was
+// A/B-tested against the product kernel and not adopted (one per-lane offset register for all weight pieces, V first in
+// LDS, constant-offset second staging piece, re-ordered transform slices).
 // Trunk 3x3 convolution (128 -> 128 channels, 15x15 board) + folded BN + (residual) + ReLU as a
 // fused F(4x4,3x3) Winograd convolution on the fp32 matrix cores -- SINGLE PASS: a work item is
 // two boards x 64 output channels with all 36 transformed positions.  gfx950 only.
