@@ -64,6 +64,17 @@ def load_mean_plies():
     return None, None
 
 
+def load_counted():
+    """The directly counted rate of the last `--count-games` run on this configuration (a committed measurement, not part
+    of this run's timed region)."""
+    if not os.path.exists(CALIB):
+        return None
+    with open(CALIB) as f:
+        c = json.load(f)
+    return {"games_per_s": c.get("games_per_s_counted"), "games": c.get("games"), "leaf_evals_per_s": c.get("leaf_evals_per_s"),
+            "source": c.get("source")}
+
+
 def _cpu_worker(budget_s):
     """One sequential self-play search loop on one core: oracle tree + oracle/net_ref.c batch-1 forward per playout."""
     from oracle.board_ref import RefBoard
@@ -450,6 +461,9 @@ def main():
                     ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "single process"),
         "leaf_evals_per_s": leafs / dt,
         "playouts_per_s": playouts / dt,
+        "value_basis": "derived: playouts of the timed region / n_playout / mean plies per game (config.mean_plies_per_game); the same "
+                       "quantity COUNTED over a steady-state window is in counted_steady_state (bench.py --count-games)",
+        "counted_steady_state": load_counted(),
         "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
         "roofline": {"kernel": kernel_name + ": trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward",
                      "bound": "mfma", "achieved": executed_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
