@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # child of cpu_baseline()
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
+    ap.add_argument("--profile-samples", type=int, default=20, help="... or more often, for at least this many timed forwards")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (gloo, stand-in evaluator from tests/fakenet.py, "
@@ -378,8 +379,12 @@ def main():
     gc.collect()
     gc.freeze()                                      # no cyclic-GC pauses inside the timed region
     gc.disable()
+    # HIP-event timing of the trunk launches: every k-th forward of the timed region, k small enough for >= 20 samples
+    # (the driver's 20-step runs have 40 forwards: three samples, the first of them right behind the idle GPU of the
+    # synchronisation below, are not an average)
+    prof_stride = max(1, min(args.profile_every, (args.steps * args.pipeline) // max(1, args.profile_samples)))
     for ln in lanes:
-        ln.set_profiling(args.profile_every)
+        ln.set_profiling(prof_stride)
     p0, l0 = playouts_done(), eng.stats["leaf_evals"]
     host0, eval0 = eng.timers["host_s"], eng.timers["eval_s"]
     dist.barrier()
