@@ -381,3 +381,22 @@ def test_small_batch_channel_groups_do_not_change_a_boards_bits():
     o = net_ref.forward(prm, planes[:48], "simple", dtype=np.float64)
     np.testing.assert_allclose(big[0][:48], o[0], rtol=0, atol=LOGIT_ATOL)
     net.close()
+
+
+def test_wino3_launch_shapes_do_not_change_a_boards_bits():
+    """`wino3_grid` gives batches with fewer board pairs than CUs two workgroups per pair (duos padded to whole groups
+    of 16 blocks), batches between 256 and 512 boards uneven duos, larger ones one workgroup per CU.  The same boards
+    through every shape: identical bits, and the float64 oracle within the path's tolerance
+    (policy_value_net_mxnet.py:77-83 through policy_value, :232-242)."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=14, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=600, n_blocks=2, n_filter=128, model_params=prm)
+    _, planes = random_positions(600, 15, seed=88)
+    big = net.forward_with_logits(planes)                        # 300 pairs: one workgroup per CU
+    for lo, n in ((0, 1), (3, 2), (10, 17), (40, 130), (100, 300), (0, 512)):
+        small = net.forward_with_logits(planes[lo:lo + n])
+        for a, b in zip(small, big):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b)[lo:lo + n], err_msg="n=%d" % n)
+    o = net_ref.forward(prm, planes[:24], "resnet", 2, np.float64)
+    np.testing.assert_allclose(big[0][:24], o[0], rtol=0, atol=LOGIT_ATOL)
+    net.close()
