@@ -21,6 +21,7 @@
 #include "trunk15_wino2.h"
 #include "trunk15_wino3.h"
 #include "wgrad_wino.h"
+#include "wgrad_wino2.h"
 #include "sampler.h"
 #include "conv_train.h"
 #include "heads_train.h"
@@ -1400,8 +1401,13 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    // 12 position groups x slices ~ two workgroups per CU, the groups of a slice on one XCD (see the kernel)
-    const int spx = std::max(1, std::min((n + 7) / 8, 2 * e->num_cu / (8 * T::GROUPS)));
+    // Decomposition by channel blocks (csrc/wgrad_wino2.h: 8 blocks x slices = one workgroup per CU) unless
+    // APZ_WGRAD_KERNEL=1 asks for the one by position groups (12 groups x slices ~ two workgroups per CU); either way
+    // the workgroups of a slice sit on one XCD (see the kernels)
+    static const bool by_blocks = !(getenv("APZ_WGRAD_KERNEL") && atoi(getenv("APZ_WGRAD_KERNEL")) == 1);
+    using T2 = apz::WgradWino2;
+    const int spx = by_blocks ? std::max(1, std::min((n + 7) / 8, e->num_cu / (8 * T2::BLOCKS)))
+                              : std::max(1, std::min((n + 7) / 8, 2 * e->num_cu / (8 * T::GROUPS)));
     const int slices = 8 * spx;
     if (slices > e->wgw_slices) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1416,8 +1422,19 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
                                     T::LDS_BYTES));
         attr = true;
     }
-    hipLaunchKernelGGL(apz::wgrad_wino_kernel, dim3(T::GROUPS * slices), dim3(T::THREADS), T::LDS_BYTES, e->stream,
-                       (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
+    if (by_blocks) {
+        bool& attr2 = e->lds_attr_set[10];
+        if (!attr2) {
+            HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        T2::LDS_BYTES));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(apz::wgrad_wino2_kernel, dim3(T2::BLOCKS * slices), dim3(T2::THREADS), T2::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
+    } else {
+        hipLaunchKernelGGL(apz::wgrad_wino_kernel, dim3(T::GROUPS * slices), dim3(T::THREADS), T::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
+    }
     hipLaunchKernelGGL(apz::wgrad_wino_sum_kernel, dim3(36 * 128 * 128 / 4 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
                        slices);
     hipLaunchKernelGGL(apz::wgrad_wino_reduce_kernel, dim3(128 * 128 / 256), dim3(256), 0, e->stream, e->wgw_scratch,

@@ -1,0 +1,291 @@
+// Weight gradient of the trunk convolution (128 -> 128, 15x15) through the Winograd F(4x4,3x3) domain, decomposed by
+// CHANNEL BLOCKS.  gfx950.  Same mathematics and same scratch layout as wgrad_wino.h (its sum / reduce kernels finish
+// the job); what changes is who does what:
+//
+//   dU[pos][co][ci] = sum over boards and tiles of dM[pos][co][tile] * V[pos][ci][tile],  dM = A dY A^T,  V = B^T d B.
+//
+// wgrad_wino_kernel gives a workgroup three of the 36 positions and all 128 x 128 channel pairs: every board's 256
+// planes are read by twelve workgroups (2.9 MB of L2 -> CU traffic per board, 1.5 GB per 512-board launch), and each of
+// them repeats the first transform stage of every (plane, tile) for its own position row (3 220 VALU instructions per
+// workgroup and board against 768 MFMAs).  Here a workgroup owns a block of 64 output x 32 input channels with ALL 36
+// positions (8 waves x 144 accumulator registers, as in the forward kernel): a board's planes are read by two (input)
+// or four (gradient) workgroups, and every (plane, tile) is transformed once per reader, completely -- 66 / 80 VALU
+// lane-operations for all 36 positions instead of ~40 for three.
+//
+// One workgroup (512 threads) per CU.  The operands of a whole board for 36 positions do not fit LDS (221 KB), so a
+// board is processed in two halves of two tile rows (8 tiles = two MFMA k-steps): per half six chunks of 16 planes
+// (two input chunks, four gradient chunks) stream through a raw area of three buffers by LDS-DMA (two chunks in
+// flight), six waves transform a chunk (wave = tile row x one of three pairs of transform rows; lane = channel x tile
+// of the row, the four tiles of a row in one quad so that the patch's halo columns come from neighbouring lanes), two
+// waves are the loaders; then all eight waves run the half's MFMAs: wave = (nine positions) x (two of the four
+// output-channel groups) x both input-channel groups, four operand reads per four MFMAs, requested one step ahead.
+// The price of the halves: every plane passes through LDS twice (the second time from L2).
+//
+// LDS: raw [3][16 planes][244] (planes padded to 976 bytes: sixteen lanes that read the same tile of sixteen planes
+// would otherwise sit on two banks), V [36][2 groups][8 tiles][16], dM [36][4 groups][8 tiles][16]; channel c of tile t
+// sits in slot c ^ 8 (t >> 1 & 1) of its group row, which makes the transform's writes and the MFMA's reads both
+// conflict-free.  157.4 KB.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wgrad_wino.h"
+
+#ifndef APZ_WGW2_NO_TRANSFORM
+#define APZ_WGW2_NO_TRANSFORM 0   /* measurement builds: skip the transforms / the MFMA phase */
+#endif
+#ifndef APZ_WGW2_NO_MFMA
+#define APZ_WGW2_NO_MFMA 0
+#endif
+
+namespace apz {
+
+struct WgradWino2 {
+    static constexpr int C = 128, CO_B = 64, CI_B = 32, BLOCKS = (C / CO_B) * (C / CI_B);   // 8 channel blocks
+    static constexpr int GPLANE = 240, RSTRIDE = 244;                   // plane as stored / as staged in LDS (floats)
+    static constexpr int CK = 16, CHUNKS = (CI_B + CO_B) / CK;          // 6 chunks per half board: 2 input, 4 gradient
+    static constexpr int RAW_FLOATS = CK * RSTRIDE;                     // 3904 per buffer
+    static constexpr int OPV_FLOATS = 36 * (CI_B / 16) * 128;           // 9216
+    static constexpr int OPM_FLOATS = 36 * (CO_B / 16) * 128;           // 18432
+    static constexpr int NBUF = 3;                                      // raw buffers: chunks u + 1, u + 2 are in flight while u is transformed
+    static constexpr int LDS_FLOATS = NBUF * RAW_FLOATS + OPV_FLOATS + OPM_FLOATS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;                    // 157 440
+    static constexpr int THREADS = 512;
+};
+static_assert(WgradWino2::LDS_BYTES <= 160 * 1024, "LDS");
+
+// x, dy: padded-row layout [n][128][15][16].  scratch: [slices][36][128 co][128 ci] (partial dU per batch slice).
+// Grid: 8 * BLOCKS * spx workgroups, slices = 8 * spx.  Workgroup L (dispatched round-robin over the XCDs, L mod 8 = its
+// XCD) takes slice (L mod 8) * spx + (L / 8) / BLOCKS and channel block (L / 8) mod BLOCKS: the eight blocks of a slice
+// read the same boards and sit on one XCD, so all but the first read of a plane is an L2 hit.
+__global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ scratch, int n, int spx) {
+    using T = WgradWino2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* raw = lds;                                 // [NBUF][16][RSTRIDE]
+    float* opv = lds + T::NBUF * T::RAW_FLOATS;       // V  [36][2][8 tiles][16]
+    float* opm = opv + T::OPV_FLOATS;                 // dM [36][4][8 tiles][16]
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+
+    const int wg_k = blockIdx.x >> 3;
+    const int blk = wg_k % T::BLOCKS, cob = blk >> 2, cib = blk & 3;
+    const int slice = (blockIdx.x & 7) * spx + wg_k / T::BLOCKS, slices = 8 * spx;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, j = lane & 15;
+
+    // ---- MFMA roles: wave = (position group pg: positions 9 pg .. 9 pg + 8) x (output-channel groups 2 cc, 2 cc + 1)
+    const int pg = wave & 3, cc = wave >> 2;
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int p = 0; p < 9; p++)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[p][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- transform roles (waves 0..5): tile row tr of the half, row pair `role` of the first transform stage;
+    // lane = (channel of the chunk uch, tile column ttx): the four tiles of a tile row are the four lanes of a quad.
+    // (Eight symmetric waves -- four row sets per unit, every wave moving two planes of the next chunk -- were measured
+    // SLOWER: 238 us against 203 us per 512-board launch.)
+    const int tr = wave & 1, role = wave >> 1;
+    const int ttx = lane & 3, uch = lane >> 2;
+    const int wslot = (tr * 4 + ttx) * 16 + (uch ^ (8 * (ttx >> 1)));   // (tile of the half, swizzled channel slot)
+    // ---- loader roles (waves 6, 7): plane 8 (wave - 6) + i of the chunk, i = 0..7; lanes 0..59 move its 960 bytes
+    const int lw = wave - 6;
+
+    // stream of this workgroup: unit u = (board of the slice, half, chunk); chunk c < 2: input planes
+    // 32 cib + 16 c .., else gradient planes 64 cob + 16 (c - 2) ..
+    const int nboards = slice < n ? (n - slice + slices - 1) / slices : 0;
+    const int total = nboards * 2 * T::CHUNKS;
+    auto issue = [&](int u, int buf) {                // (loader waves) request chunk u into raw buffer `buf`
+        if (u >= total) return;
+        const int bi = u / (2 * T::CHUNKS), c = u % T::CHUNKS;
+        const int b = slice + bi * slices;
+        const float* src = (c < 2 ? x + ((size_t)b * T::C + cib * T::CI_B + c * 16) * T::GPLANE
+                                  : dy + ((size_t)b * T::C + cob * T::CO_B + (c - 2) * 16) * T::GPLANE);
+        if (lane < 60) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int pl = lw * 8 + i;
+                wgw_dma16(src + pl * T::GPLANE + lane * 4, lds_base + (buf * T::RAW_FLOATS + pl * T::RSTRIDE) * 4);
+            }
+        }
+    };
+    if (wave >= 6) {
+        issue(0, 0);
+        issue(1, 1);
+    }
+
+    for (int u = 0; u < total; u++) {
+        const int buf = u % T::NBUF;
+        const int c = u % T::CHUNKS, hh = (u / T::CHUNKS) & 1;
+        // this loader's eight planes of chunk u have landed: loads retire in order, the youngest eight (chunk u + 1) may
+        // still be in flight (past the end of the stream nothing was issued: wait for everything)
+        if (wave >= 6) {
+            if (u + 1 < total)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                              // ... everybody's; chunk u - 1 (and a finished half's MFMAs) consumed
+        if (wave >= 6) {
+            issue(u + 2, (u + 2) % T::NBUF);          // into the buffer chunk u - 1 has just left
+        } else if (!APZ_WGW2_NO_TRANSFORM) {
+            const float* rb = raw + buf * T::RAW_FLOATS + uch * T::RSTRIDE;
+            const int trow = 2 * hh + tr;             // tile row of the board (wave-uniform)
+            if (c < 2) {
+                // ---- V = B^T d B of (input channel 16 c + uch, tile (trow, ttx)): rows y[2] of B^T d for this role
+                float y[2][6];
+                auto row6 = [&](int i, float* v) {    // patch row i (board row 4 trow - 1 + i), columns -1 .. 4
+                    const int R = 4 * trow - 1 + i;
+                    const bool in = R >= 0 && R <= 14;                  // (wave-uniform)
+                    const f32x4 c03 = in ? *reinterpret_cast<const f32x4*>(rb + (in ? R : 0) * 16 + 4 * ttx) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[0] = wgw_quad_neighbour<false>(c03[3], ttx);
+                    v[1] = c03[0];
+                    v[2] = c03[1];
+                    v[3] = c03[2];
+                    v[4] = c03[3];
+                    v[5] = wgw_quad_neighbour<true>(c03[0], ttx);
+                };
+                int i0, i1;                           // the two output rows of this role
+                if (role == 0) {
+                    float x0[6], x2[6], x4[6], x1[6], x3[6], x5[6];
+                    row6(0, x0); row6(2, x2); row6(4, x4); row6(1, x1); row6(3, x3); row6(5, x5);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        y[0][k] = __builtin_fmaf(4.f, x0[k], __builtin_fmaf(-5.f, x2[k], x4[k]));
+                        y[1][k] = __builtin_fmaf(4.f, x1[k], __builtin_fmaf(-5.f, x3[k], x5[k]));
+                    }
+                    i0 = 0; i1 = 5;
+                } else {
+                    float x1[6], x2[6], x3[6], x4[6];
+                    row6(1, x1); row6(2, x2); row6(3, x3); row6(4, x4);
+                    if (role == 1) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            const float a = __builtin_fmaf(-4.f, x2[k], x4[k]), b = __builtin_fmaf(-4.f, x1[k], x3[k]);
+                            y[0][k] = a + b;
+                            y[1][k] = a - b;
+                        }
+                        i0 = 1; i1 = 2;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            const float cdiff = x4[k] - x2[k], d = x3[k] - x1[k];
+                            y[0][k] = __builtin_fmaf(2.f, d, cdiff);
+                            y[1][k] = __builtin_fmaf(-2.f, d, cdiff);
+                        }
+                        i0 = 3; i1 = 4;
+                    }
+                }
+                float* dst = opv + c * 128 + wslot;   // group c of the block's two input-channel groups
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const float* v = y[rr];
+                    const float a = __builtin_fmaf(-4.f, v[2], v[4]), b = __builtin_fmaf(-4.f, v[1], v[3]);
+                    const float cdiff = v[4] - v[2], d = v[3] - v[1];
+                    float o[6];
+                    o[0] = __builtin_fmaf(4.f, v[0], __builtin_fmaf(-5.f, v[2], v[4]));
+                    o[1] = a + b;
+                    o[2] = a - b;
+                    o[3] = __builtin_fmaf(2.f, d, cdiff);
+                    o[4] = __builtin_fmaf(-2.f, d, cdiff);
+                    o[5] = __builtin_fmaf(4.f, v[1], __builtin_fmaf(-5.f, v[3], v[5]));
+                    const int ir = rr == 0 ? i0 : i1;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) dst[(ir * 6 + k) * 256] = o[k];      // V: 2 groups x 128 floats per position
+                }
+            } else {
+                // ---- dM = A dY A^T of (output channel 16 (c - 2) + uch, tile (trow, ttx)): rows m[2] of A dY for this role
+                auto row4 = [&](int i) {              // tile row i (board row 4 trow + i), columns 0 .. 3
+                    const int R = 4 * trow + i;
+                    const bool in = R <= 14;
+                    return in ? *reinterpret_cast<const f32x4*>(rb + (in ? R : 0) * 16 + 4 * ttx) : f32x4{0.f, 0.f, 0.f, 0.f};
+                };
+                f32x4 m0, m1;
+                int i0, i1;
+                if (role == 0) {
+                    m0 = row4(0);
+                    m1 = row4(3);
+                    i0 = 0; i1 = 5;
+                } else {
+                    const f32x4 d0 = row4(0), d1 = row4(1), d2 = row4(2), d3 = row4(3);
+                    if (role == 1) {
+                        const f32x4 s02 = d0 + d2, s13 = d1 + d3;
+                        m0 = s02 + s13;
+                        m1 = s02 - s13;
+                        i0 = 1; i1 = 2;
+                    } else {
+                        const f32x4 sv = d0 + 4.f * d2, tv = 2.f * d1 + 8.f * d3;
+                        m0 = sv + tv;
+                        m1 = sv - tv;
+                        i0 = 3; i1 = 4;
+                    }
+                }
+                float* dst = opm + (c - 2) * 128 + wslot;   // group c - 2 of the block's four output-channel groups
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const f32x4 w = rr == 0 ? m0 : m1;
+                    const float s02 = w[0] + w[2], s13 = w[1] + w[3];
+                    const float sv = __builtin_fmaf(4.f, w[2], w[0]), tv = __builtin_fmaf(8.f, w[3], 2.f * w[1]);
+                    float o[6];
+                    o[0] = w[0];
+                    o[1] = s02 + s13;
+                    o[2] = s02 - s13;
+                    o[3] = sv + tv;
+                    o[4] = sv - tv;
+                    o[5] = w[3];
+                    const int ir = rr == 0 ? i0 : i1;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) dst[(ir * 6 + k) * 512] = o[k];      // dM: 4 groups x 128 floats per position
+                }
+            }
+        }
+        if (c == T::CHUNKS - 1 && !APZ_WGW2_NO_MFMA) {
+            __syncthreads();                          // the half's operand arrays are complete
+            // ---- dU[pos][co][ci] += dM[pos][co][tile] * V[pos][ci][tile] over the half's 8 tiles (two k-steps):
+            // A = dM (m = co), B = V (n = ci), k = tile; lane (q, j): tile 4 s + q, channel slot j ^ 8 (q >> 1)
+            // Operands are requested one step (position, k-step) ahead of their four MFMAs and the order is pinned:
+            // left alone hipcc puts every step's four LDS reads right in front of its MFMAs and waits out the LDS
+            // latency eighteen times per half (the phase then runs at 45 % of the matrix pipe).
+            auto fetch = [&](int st, float* o) {      // step st = 2 p + s
+                const int pos = pg * 9 + (st >> 1), sk = st & 1;
+                const int slot = (4 * sk + q) * 16 + (j ^ (8 * (q >> 1)));
+                o[0] = opm[(pos * 4 + 2 * cc) * 128 + slot];
+                o[1] = opm[(pos * 4 + 2 * cc + 1) * 128 + slot];
+                o[2] = opv[(pos * 2) * 128 + slot];
+                o[3] = opv[(pos * 2 + 1) * 128 + slot];
+            };
+            float cur[4], nxt[4];
+            fetch(0, cur);
+#pragma unroll
+            for (int st = 0; st < 18; st++) {
+                if (st + 1 < 18) fetch(st + 1, nxt);
+                const int p = st >> 1;
+                acc[p][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[0], cur[2], acc[p][0][0], 0, 0, 0);
+                acc[p][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[0], cur[3], acc[p][0][1], 0, 0, 0);
+                acc[p][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[1], cur[2], acc[p][1][0], 0, 0, 0);
+                acc[p][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[1], cur[3], acc[p][1][1], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- partial dU of this slice and channel block: accumulator (p, a, b), lane (q, j), register r ->
+    // pos = 9 pg + p, co = 64 cob + 16 (2 cc + a) + 4 q + r, ci = 32 cib + 16 b + j
+    float* out = scratch + (size_t)slice * WgradWino::SCRATCH_FLOATS_PER_SLICE;
+#pragma unroll
+    for (int p = 0; p < 9; p++)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    out[((size_t)(pg * 9 + p) * T::C + cob * T::CO_B + (2 * cc + a) * 16 + 4 * q + r) * T::C + cib * T::CI_B +
+                        b * 16 + j] = acc[p][a][b][r];
+}
+
+}  // namespace apz
