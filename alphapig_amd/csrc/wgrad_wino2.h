@@ -19,7 +19,7 @@
 // of the row, the four tiles of a row in one quad so that the patch's halo columns come from neighbouring lanes), two
 // waves are the loaders; then all eight waves run the half's MFMAs: wave = (nine positions) x (two of the four
 // output-channel groups) x both input-channel groups, four operand reads per four MFMAs, requested one step ahead.
-// The price of the halves: every plane passes through LDS twice (the second time from L2).
+// Each half requests only the rows of a plane its tiles look at (9 + 8 of 15 input rows, 8 + 7 gradient rows).
 //
 // LDS: raw [3][16 planes][244] (planes padded to 976 bytes: sixteen lanes that read the same tile of sixteen planes
 // would otherwise sit on two banks), V [36][2 groups][8 tiles][16], dM [36][4 groups][8 tiles][16]; channel c of tile t
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
 
     // ---- transform roles (waves 0..5): tile row tr of the half, row pair `role` of the first transform stage;
     // lane = (channel of the chunk uch, tile column ttx): the four tiles of a tile row are the four lanes of a quad.
-    // (Eight symmetric waves -- four row sets per unit, every wave moving two planes of the next chunk -- were measured
-    // SLOWER: 238 us against 203 us per 512-board launch.)
+    // (Eight transform waves -- four row sets per unit: {0}, {5}, {1, 2}, {3, 4} / {0, 1}, {2, 5}, {3}, {4} -- were measured
+    // SLOWER, with the loads spread over all waves or kept on two: 238 / 250 us against 202 us per 512-board launch.)
     const int tr = wave & 1, role = wave >> 1;
     const int ttx = lane & 3, uch = lane >> 2;
     const int wslot = (tr * 4 + ttx) * 16 + (uch ^ (8 * (ttx >> 1)));   // (tile of the half, swizzled channel slot)
@@ -104,11 +104,16 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
         const int b = slice + bi * slices;
         const float* src = (c < 2 ? x + ((size_t)b * T::C + cib * T::CI_B + c * 16) * T::GPLANE
                                   : dy + ((size_t)b * T::C + cob * T::CO_B + (c - 2) * 16) * T::GPLANE);
-        if (lane < 60) {
+        // only the rows this half's tiles look at (input: patch rows -1 .. 8 / 7 .. 16 of the board, gradient: rows
+        // 0 .. 7 / 8 .. 14): 1 088 / 960 bytes per plane for both halves together instead of 2 x 960
+        const int hh = (u / T::CHUNKS) & 1;
+        const int r0 = c < 2 ? (hh ? 7 : 0) : (hh ? 8 : 0), r1 = c < 2 ? (hh ? 15 : 9) : (hh ? 15 : 8);   // rows [r0, r1)
+        if (lane < 4 * (r1 - r0)) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int pl = lw * 8 + i;
-                wgw_dma16(src + pl * T::GPLANE + lane * 4, lds_base + (buf * T::RAW_FLOATS + pl * T::RSTRIDE) * 4);
+                wgw_dma16(src + pl * T::GPLANE + r0 * 16 + lane * 4,
+                          lds_base + (buf * T::RAW_FLOATS + pl * T::RSTRIDE + r0 * 16) * 4);
             }
         }
     };
