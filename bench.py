@@ -375,10 +375,10 @@ def main():
         raise SystemExit("profiles/calibration_r02.json missing: run `python bench.py --count-games 240` once")
 
     import gc
-    eng.run_steps(args.warmup)                       # W untimed warm-up steps
     gc.collect()
-    gc.freeze()                                      # no cyclic-GC pauses inside the timed region
-    gc.disable()
+    gc.freeze()                                      # no cyclic-GC pauses inside the timed region ...
+    gc.disable()                                     # ... and no collection BETWEEN warm-up and timed region: tens of ms of idle GPU
+    eng.run_steps(args.warmup)                       # W untimed warm-up steps
     # HIP-event timing of the trunk launches: every k-th forward of the timed region, k small enough for >= 20 samples
     # (the driver's 20-step runs have 40 forwards: three samples, the first of them right behind the idle GPU of the
     # synchronisation below, are not an average)
