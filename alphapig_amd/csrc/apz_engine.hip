@@ -243,8 +243,8 @@ struct Timed {
     int cls;
     int launches = 1;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(apz_engine* e_, int cls_) : e(e_), cls(cls_) {
-        if (e->profiling && e->prof_now) {
+    Timed(apz_engine* e_, int cls_, bool always = false) : e(e_), cls(cls_) {
+        if (e->profiling && (e->prof_now || always)) {
             a = get_event(e);
             b = get_event(e);
             hipEventRecord(a, e->stream);
@@ -257,6 +257,23 @@ struct Timed {
         }
     }
 };
+
+// Recycle the pairs whose closing event has already fired (oldest first: one stream, events complete in order), so
+// that a long profiled run keeps a handful of events alive instead of creating thousands.
+void resolve_ready(apz_engine* e) {
+    size_t k = 0;
+    while (k < e->pending.size() && hipEventQuery(e->pending[k].b) == hipSuccess) {
+        Pending& p = e->pending[k++];
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            e->k_ms[p.cls] += ms;
+            e->k_cnt[p.cls] += p.launches;
+        }
+        e->free_events.push_back(p.a);
+        e->free_events.push_back(p.b);
+    }
+    if (k) e->pending.erase(e->pending.begin(), e->pending.begin() + k);
+}
 
 void resolve_pending(apz_engine* e) {
     for (auto& p : e->pending) {
@@ -506,6 +523,10 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
     if (n < 0 || n > e->cfg.max_batch) return fail(APZ_E_ARG, "batch exceeds max_batch");
     if (n == 0) return APZ_OK;
     e->prof_now = e->profiling && (e->prof_phase++ % e->prof_stride == 0);
+    if (e->profiling) resolve_ready(e);
+    // the whole forward under one pair, EVERY forward while profiling is on: sum / wall clock = the GPU-busy fraction of a
+    // measured window (two records per ~2 ms forward, at the forward's edges where the slot's `done` event sits anyway)
+    Timed whole(e, APZ_K_FORWARD, true);
     float* trunk = nullptr;
     int rc = run_trunk(e, planes, n, (int)e->convs.size() - 1, &trunk, codes_dev);
     if (rc) return rc;
@@ -677,6 +698,7 @@ apz_engine* apz_create(const apz_config* cfg) {
     if ((err = hipMalloc((void**)&e->fc_logits, B * ((hw + 15) / 16 * 16) * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->values, B * sizeof(float))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void**)&e->codes, B * e->code_stride)) != hipSuccess) return bail("hipMalloc", err);
+    if ((err = hipMemset(e->codes, 0, B * e->code_stride)) != hipSuccess) return bail("hipMemset(codes)", err);   // empty boards: apz_prewarm's input
     if ((err = hipHostMalloc((void**)&e->h_planes, B * 9 * hw * sizeof(float))) != hipSuccess) return bail("hipHostMalloc", err);
     if ((err = hipHostMalloc((void**)&e->h_probs, B * hw * sizeof(float))) != hipSuccess) return bail("hipHostMalloc", err);
     if ((err = hipHostMalloc((void**)&e->h_values, B * sizeof(float))) != hipSuccess) return bail("hipHostMalloc", err);
@@ -1635,6 +1657,26 @@ int apz_layout_convert(apz_engine* e, const void* src_dev, void* dst_dev, int64_
         hipLaunchKernelGGL(apz::rows16_to_dense_kernel, dim3(grid), dim3(256), 0, e->stream, (const float*)src_dev, (float*)dst_dev,
                            (long)planes);
     HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_prewarm(apz_engine* e, int n, int iters) {
+    if (!e) return fail(APZ_E_ARG, "null engine");
+    if (n < 1 || n > e->cfg.max_batch || iters < 0) return fail(APZ_E_ARG, "prewarm: bad batch / iteration count");
+    EngineLock guard(e->submit_lock);
+    if (!e->loaded) return fail(APZ_E_STATE, "weights not loaded");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    // e->codes is zero-filled at creation and only ever overwritten with valid codes: any content is a legal input
+    for (int i = 0; i < iters; i++) {
+        int rc;
+        if (stem_takes_codes(e)) {
+            rc = forward_dev(e, nullptr, n, e->probs, e->values, nullptr, nullptr, e->codes);
+        } else {
+            rc = apz_encode_planes(e, e->codes, n, e->cfg.c_in, e->planes);
+            if (!rc) rc = forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
+        }
+        if (rc) return rc;
+    }
     return APZ_OK;
 }
 

@@ -17,7 +17,7 @@ import numpy as np
 from . import _native, weights
 from ._native import ApzConfig, as_ptr
 
-KERNEL_CLASSES = {"stem": 0, "trunk": 1, "head_conv": 2, "head_fc": 3, "encode": 4}
+KERNEL_CLASSES = {"stem": 0, "trunk": 1, "head_conv": 2, "head_fc": 3, "encode": 4, "forward": 5}
 
 
 class EvaluatorError(RuntimeError):
@@ -283,6 +283,11 @@ class PolicyValueNet(object):
         out = np.zeros(2, dtype=np.float32)
         self._ck(self.L.apz_kernel_time_ms(self._h, KERNEL_CLASSES[kernel_class], as_ptr(out, C.c_float)))
         return float(out[0]), int(out[1])
+
+    def prewarm(self, n, iters):
+        """Enqueue `iters` forwards of n empty boards on the engine stream, without waiting (GPU-only warm-up of a
+        measurement: clocks, runtime pools; results are never read)."""
+        self._ck(self.L.apz_prewarm(self._h, int(n), int(iters)))
 
     def sync(self):
         self._ck(self.L.apz_sync(self._h))

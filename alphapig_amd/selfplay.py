@@ -87,6 +87,7 @@ class SelfPlayEngine(object):
         self.finished = []
         self.stats = collections.Counter()
         self.timers = collections.Counter()
+        self.step_times = None          # bench.py sets a list: wall time of every scheduler round lands there
         self._limit = None
         n_workers = min(self.pipeline, getattr(self.evaluator, "n_slots", 1)) if self._slotted else 1
         # one worker thread per slot; a worker serves its own groups in order
@@ -238,8 +239,10 @@ class SelfPlayEngine(object):
         leafs = 0
         groups = self._groups()
         inflight = {}
+        step_times = getattr(self, "step_times", None)      # measurement hook (bench.py): wall time of every scheduler round
         for _ in range(n_steps):
             busy = False
+            t_step = time.perf_counter()
             for gi, grp in enumerate(groups):
                 if gi in inflight:                       # finish this group's previous evaluation
                     ids, fut = inflight.pop(gi)
@@ -256,6 +259,8 @@ class SelfPlayEngine(object):
                         inflight[gi] = (ids, self._exec[w].submit(self._evaluate, codes, w))
                     else:
                         inflight[gi] = (ids, self._evaluate(codes))
+            if step_times is not None:
+                step_times.append(time.perf_counter() - t_step)
             if not busy:
                 break
         for gi in sorted(inflight):

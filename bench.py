@@ -238,6 +238,10 @@ def main():
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--profile-samples", type=int, default=20, help="... or more often, for at least this many timed forwards")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
+    ap.add_argument("--prewarm-s", type=float, default=0.6,
+                    help="declared UNTIMED GPU-only pre-warm before the W warm-up steps: dummy forwards of empty boards "
+                         "(not engine steps) for this many seconds, plus 4 dummy forwards queued right before the closing "
+                         "synchronisation of the warm-up so that the timed region starts on a GPU at its running clocks; 0 = off")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (gloo, stand-in evaluator from tests/fakenet.py, "
                          "8 games per rank); the JSON line is marked invalid and is NOT a measurement")
@@ -378,18 +382,42 @@ def main():
     gc.collect()
     gc.freeze()                                      # no cyclic-GC pauses inside the timed region ...
     gc.disable()                                     # ... and no collection BETWEEN warm-up and timed region: tens of ms of idle GPU
-    eng.run_steps(args.warmup)                       # W untimed warm-up steps
     # HIP-event timing of the trunk launches: every k-th forward of the timed region, k small enough for >= 20 samples
     # (the driver's 20-step runs have 40 forwards: three samples, the first of them right behind the idle GPU of the
-    # synchronisation below, are not an average)
+    # synchronisation below, are not an average); every forward as a whole is bracketed too (-> gpu_busy_frac)
     prof_stride = max(1, min(args.profile_every, (args.steps * args.pipeline) // max(1, args.profile_samples)))
-    for ln in lanes:
-        ln.set_profiling(prof_stride)
+    batch = G // args.pipeline
+    # Declared, untimed, GPU-only pre-warm (profiles/r03_driver_window.md): a GPU that has just been idle runs the trunk
+    # kernel at 118-127 us per launch and needs ~40 forwards (80 ms) to reach its running 98 us, and the first few
+    # hundred launches / timing events of a process pay the HIP runtime's pool growth (ms-long host stalls).  With
+    # W = 5 both landed inside the driver's 0.1 s window.  These are dummy forwards of empty boards on the evaluator's
+    # stream -- no engine step, no playout is done here; `steps` and `warmup` keep their meaning.
+    prewarm = {"seconds": 0.0, "dummy_forwards": 0, "keep_warm_forwards": 0, "boards_per_forward": batch,
+               "what": "untimed GPU-only dummy forwards of empty boards before the warm-up steps (+ a few queued right before the "
+                       "synchronisation that closes the warm-up): clock ramp and HIP runtime pool growth; no engine steps"}
+    eng.run_steps(0)                                 # seeds the G games (tens of ms of host work) BEFORE the GPU is warmed
+    if args.prewarm_s > 0 and not args.plumbing_test:
+        t_pw = time.perf_counter()
+        for ln in lanes:
+            ln.set_profiling(prof_stride)            # the event path is part of what has to be warm
+        while time.perf_counter() - t_pw < args.prewarm_s:
+            for ln in lanes:
+                ln.prewarm(batch, 8)
+            for ln in lanes:
+                ln.sync()
+            prewarm["dummy_forwards"] += 8
+        prewarm["seconds"] = time.perf_counter() - t_pw
+    eng.run_steps(args.warmup)                       # W untimed warm-up steps
+    if args.prewarm_s > 0 and not args.plumbing_test:
+        for ln in lanes:
+            ln.prewarm(batch, 4)                     # keeps the GPU busy across the bookkeeping below (not waited for here)
+        prewarm["keep_warm_forwards"] = 4
     p0, l0 = playouts_done(), eng.stats["leaf_evals"]
     host0, eval0 = eng.timers["host_s"], eng.timers["eval_s"]
+    eng.step_times = []
     dist.barrier()
     for ln in lanes:
-        ln.sync()                                    # == torch.cuda.synchronize() for the engine streams
+        ln.set_profiling(prof_stride)                # stream synchronize (== torch.cuda.synchronize() for the engine stream) + counters reset
     t0 = time.perf_counter()
     eng.run_steps(args.steps)                        # exactly K timed steps
     # the round's exchange: all-gather of the tuples of games that finished inside the window
@@ -412,10 +440,12 @@ def main():
     ranks_seen = int(round(dist.all_reduce_sum(1)))
     playouts = dist.all_reduce_sum(playouts_done() - p0)
     leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0)
-    trunk_ms = trunk_cnt = 0
+    trunk_ms = trunk_cnt = fwd_ms = fwd_cnt = 0
     for ln in lanes:
         ms_, cnt_ = ln.kernel_time_ms("trunk")
         trunk_ms, trunk_cnt = trunk_ms + ms_, trunk_cnt + cnt_
+        ms_, cnt_ = ln.kernel_time_ms("forward")
+        fwd_ms, fwd_cnt = fwd_ms + ms_, fwd_cnt + cnt_
         ln.set_profiling(False)
     if rank != 0:
         eng.close()
@@ -424,7 +454,7 @@ def main():
         return
 
     games_per_s = playouts / N_PLAYOUT / mean_plies / dt
-    batch = G // args.pipeline
+    st_ms = sorted(1e3 * x for x in getattr(eng, "step_times", []))
     # which trunk kernel ran (apz_engine.hip reads the same variable; default = the single-pass Winograd pair kernel)
     tk = os.environ.get("APZ_TRUNK_KERNEL", "wino3")
     tk = tk if tk in ("ring", "wino", "wino2") else "wino3"
@@ -468,8 +498,17 @@ def main():
         "playouts_per_s": playouts / dt,
         "value_basis": "derived: playouts of the timed region / n_playout / mean plies per game (config.mean_plies_per_game); the same "
                        "quantity COUNTED over a steady-state window is in counted_steady_state (bench.py --count-games)",
-        "counted_steady_state": load_counted(),
+        "counted_steady_state": dict(load_counted() or {}, note="COMMITTED builder-run measurement (bench.py --count-games), echoed "
+                                     "for context; NOT measured by this run"),
         "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
+        # GPU time of the timed region: every forward (stem .. value head, kernels back to back) bracketed by one HIP
+        # event pair on the engine stream; busy fraction = their sum / wall clock of the timed region (rank 0)
+        "gpu_busy_frac": (fwd_ms * 1e-3 / dt_local) if fwd_cnt else None,
+        "kernel_ms_per_step": (fwd_ms / args.steps) if fwd_cnt else None,
+        "forwards_timed": fwd_cnt,
+        "gpu_bound": bool(fwd_cnt and fwd_ms * 1e-3 / dt_local >= 0.95),
+        "step_ms": ({"median": st_ms[len(st_ms) // 2], "max": st_ms[-1], "min": st_ms[0]} if st_ms else None),
+        "prewarm": prewarm,
         "roofline": {"kernel": kernel_name + ": trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward",
                      "bound": "mfma", "achieved": executed_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                      "frac": (executed_tf / FP32_MATRIX_PEAK_TF) if executed_tf else None,

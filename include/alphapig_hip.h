@@ -41,7 +41,8 @@ extern "C" {
 #define APZ_K_HEAD_CONV 2
 #define APZ_K_HEAD_FC 3
 #define APZ_K_ENCODE 4
-#define APZ_K_COUNT 5
+#define APZ_K_FORWARD 5   /* one whole forward (stem .. value head): EVERY forward while profiling is on, not only the sampled ones */
+#define APZ_K_COUNT 6
 
 typedef struct apz_engine apz_engine;
 
@@ -247,6 +248,10 @@ int apz_layer_io(apz_engine *e, int layer, float *host_out, int64_t count);
  * (resolved at apz_sync). */
 int apz_set_profiling(apz_engine *e, int on);
 int apz_kernel_time_ms(apz_engine *e, int kernel_class, float *out2);
+/* Enqueue `iters` forwards of n empty boards on the engine's stream and return without waiting (apz_sync waits).
+ * GPU-only warm-up for measurements: clocks, the runtime's event / signal pools, instruction caches.  The results go
+ * to the engine's device buffers and are never read; pending submissions are not disturbed (same stream, in order). */
+int apz_prewarm(apz_engine *e, int n, int iters);
 
 #ifdef __cplusplus
 }
