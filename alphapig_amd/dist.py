@@ -62,6 +62,22 @@ def barrier():
         dist.barrier()
 
 
+def shutdown():
+    """Leave the process group in an orderly way (barrier, then destroy): a rank that simply returns while its
+    peers are still inside the last collective can take the backend's worker threads down mid-flight
+    ("terminate called without an active exception" from gloo on a loaded host)."""
+    global _ACTIVE
+    if not _ACTIVE:
+        return
+    import torch.distributed as dist
+    if dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+    _ACTIVE = False
+
+
 def all_reduce_max(x):
     if not _ACTIVE:
         return float(x)
@@ -84,6 +100,20 @@ def all_reduce_sum(x):
     t = torch.tensor([float(x)], dtype=torch.float64, device=_device())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_gather_floats(x):
+    """One float per rank -> the list over ranks, in rank order (per-rank rates of a measurement)."""
+    if not _ACTIVE:
+        return [float(x)]
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return [float(x)]
+    dev = _device()
+    out = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, torch.tensor([float(x)], dtype=torch.float64, device=dev))
+    return [float(v) for v in out.cpu()]
 
 
 def all_gather_tuples(codes, pis, zs):

@@ -155,13 +155,30 @@ def stem_roofline(device):
     return out
 
 
-def spawn_ranks(n, argv):
-    """`--gpus N` outside a launcher: start N fresh rank processes (this process has not touched the GPU and
-    never does), pass rank 0's JSON line through, fail if any rank fails."""
+def _rank_log_dir():
+    d = os.path.join(REPO, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        return d
+    except OSError:
+        import tempfile
+        return tempfile.gettempdir()
+
+
+def spawn_ranks(n, argv, deadline_s=1800.0, silence_s=420.0, early_exit_grace_s=60.0):
+    """`--gpus N` outside a launcher: start N fresh rank processes (this process has not touched the GPU and never
+    does), pass rank 0's JSON line through, fail -- non-zero exit, every rank killed -- if
+      * a rank exits non-zero,
+      * a rank exits 0 while others are still running `early_exit_grace_s` later (they wait for it in a collective),
+      * the whole job passes `deadline_s`, or
+      * no rank has written a byte to its log (gpurun_out/rank<r>.log: stdout of ranks >= 1, stderr of all; ranks print
+        a heartbeat line per phase and every 20 s of a long loop) for `silence_s` -- a hung RCCL rendezvous or a wedged GPU.
+    Children are always fresh processes: nothing that has touched the GPU is ever re-executed."""
     import socket
     import subprocess
     # a port BELOW the kernel's ephemeral range (32768+): a port number the kernel handed out for bind(0) may be
-    # taken by an outgoing connection of one of the ranks before rank 0 listens on it
+    # taken by an outgoing connection of one of the ranks before rank 0 listens on it; two concurrent bench runs
+    # on one host draw independent random candidates out of 12 000
     import random
     port = None
     for _ in range(64):
@@ -176,31 +193,97 @@ def spawn_ranks(n, argv):
     if port is None:
         raise SystemExit("bench.py: no free rendezvous port in 20000..32000")
     import tempfile
-    procs = []
+    logdir = _rank_log_dir()
+    procs, logs = [], []
     out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), APZ_BENCH_SELF_SPAWNED="1")
+        lf = open(os.path.join(logdir, "rank%d.log" % r), "wb")
+        logs.append(lf)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=REPO,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
-    # a rank that dies leaves the others waiting in a collective: watch all of them, stop everything on the first failure
-    failed = None
+                                      stdout=out0 if r == 0 else lf, stderr=lf))
+    t_start = time.time()
+    failed = None                                     # (rank or None, reason)
+    first_clean_exit = None
+    last_bytes, last_change = -1, t_start
     while failed is None and any(p.poll() is None for p in procs):
         time.sleep(0.2)
+        now = time.time()
         for r, p in enumerate(procs):
-            if p.poll() not in (None, 0):
-                failed = r
+            rc = p.poll()
+            if rc not in (None, 0):
+                failed = (r, "rank %d exited with code %s" % (r, rc))
+                break
+            if rc == 0 and first_clean_exit is None:
+                first_clean_exit = (r, now)
+        if failed is not None:
+            break
+        if first_clean_exit is not None and now - first_clean_exit[1] > early_exit_grace_s:
+            failed = (first_clean_exit[0], "rank %d exited 0 but the others are still running %.0f s later" % (
+                first_clean_exit[0], early_exit_grace_s))
+        total = 0
+        for r in range(n):
+            try:
+                total += os.path.getsize(os.path.join(logdir, "rank%d.log" % r))
+            except OSError:
+                pass
+        if total != last_bytes:
+            last_bytes, last_change = total, now
+        if failed is None and now - last_change > silence_s:
+            failed = (None, "no rank wrote to its log for %.0f s (hung rendezvous / collective / GPU?)" % silence_s)
+        if failed is None and now - t_start > deadline_s:
+            failed = (None, "job deadline of %.0f s passed" % deadline_s)
     if failed is not None:
         for p in procs:
             if p.poll() is None:
                 p.kill()
         for p in procs:
             p.wait()
+    for lf in logs:
+        lf.close()
     out0.seek(0)
-    sys.stdout.write(out0.read().decode())
-    sys.stdout.flush()
-    if failed is not None:
-        raise SystemExit("bench.py: rank %d exited with code %s; stopped the other ranks" % (failed, procs[failed].returncode))
+    text = out0.read().decode()
+    if failed is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        return
+    tails = []
+    for r in range(n):
+        try:
+            with open(os.path.join(logdir, "rank%d.log" % r), "rb") as f:
+                tails.append("--- rank %d log tail ---\n%s" % (r, f.read()[-600:].decode(errors="replace")))
+        except OSError:
+            pass
+    sys.stderr.write("\n".join(tails) + "\n")
+    raise SystemExit("bench.py: %s; stopped the other ranks (logs: %s/rank*.log)" % (failed[1], logdir))
+
+
+def heartbeat(msg):
+    """One line on stderr (a rank's log under the self-spawning supervisor, which treats a long silence as a hang)."""
+    print("[bench rank %s %.1fs] %s" % (os.environ.get("RANK", "0"), time.perf_counter() - _T_PROC, msg), file=sys.stderr, flush=True)
+
+
+_T_PROC = time.perf_counter()
+
+
+def pin_rank_cpus(rank, world):
+    """Give rank r of `world` its own contiguous slice of the CPUs this job may use, BEFORE anything touches the GPU
+    (threads created later -- OpenMP workers, HIP runtime, pipeline workers -- inherit it): eight ranks' tree threads
+    otherwise migrate across both sockets.  Contiguous slices keep a rank inside one NUMA node on the usual layouts
+    (GPUs 0-3 on socket 0, 4-7 on socket 1).  APZ_BENCH_NO_AFFINITY=1 switches it off.  -> CPUs in the slice or None."""
+    if world <= 1 or os.environ.get("APZ_BENCH_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // world
+    if per < 1:
+        return None
+    mine = cpus[rank * per:(rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return len(mine)
 
 
 def host_cpu_share():
@@ -238,6 +321,10 @@ def main():
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--profile-samples", type=int, default=20, help="... or more often, for at least this many timed forwards")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
+    ap.add_argument("--deadline-s", type=float, default=1800.0, help="self-spawned ranks: kill everything after this many seconds")
+    ap.add_argument("--rank-silence-s", type=float, default=420.0,
+                    help="self-spawned ranks: kill everything when no rank has written to its log for this long")
+    ap.add_argument("--early-exit-grace-s", type=float, default=60.0, help=argparse.SUPPRESS)
     ap.add_argument("--prewarm-s", type=float, default=0.6,
                     help="declared UNTIMED GPU-only pre-warm before the W warm-up steps: dummy forwards of empty boards "
                          "(not engine steps) for this many seconds, plus 4 dummy forwards queued right before the closing "
@@ -252,18 +339,28 @@ def main():
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(args.gpus, sys.argv[1:])          # before anything touches the GPU
+        return spawn_ranks(args.gpus, sys.argv[1:], deadline_s=args.deadline_s, silence_s=args.rank_silence_s,
+                           early_exit_grace_s=args.early_exit_grace_s)     # before anything touches the GPU
     if os.environ.get("APZ_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
         raise SystemExit(3)                                  # tests/test_dist_gloo.py: a rank that dies
+    if os.environ.get("APZ_BENCH_TEST_HANG_RANK") == os.environ.get("RANK", "0"):
+        time.sleep(3600)                                     # tests/test_dist_gloo.py: a rank that hangs before the rendezvous
+    if os.environ.get("APZ_BENCH_TEST_EARLY_EXIT_RANK") == os.environ.get("RANK", "0"):
+        raise SystemExit(0)                                  # ... and one that leaves early with exit code 0
+    ncpu = host_cpu_share()                                  # the JOB's CPU share (before this rank narrows its own mask)
+    pinned = pin_rank_cpus(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))   # before any GPU call
+    heartbeat("starting (cpu slice: %s)" % pinned)
     rank, world, local = dist.init(backend="gloo" if args.plumbing_test else None)
+    heartbeat("process group up: rank %d of %d" % (rank, world))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     from alphapig_amd.policy_value_net import PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
 
     # host threads for the tree pool: this node's CPU share split evenly between its ranks
-    ncpu = host_cpu_share()
     threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(world, 1)))
+    if pinned:
+        threads = max(1, min(threads, pinned))
     G = args.games
     if args.plumbing_test:
         class _StandIn(object):      # counts like the real evaluator; numbers come from tests/fakenet.py
@@ -407,7 +504,9 @@ def main():
                 ln.sync()
             prewarm["dummy_forwards"] += 8
         prewarm["seconds"] = time.perf_counter() - t_pw
+    heartbeat("pre-warm done (%d dummy forwards)" % prewarm["dummy_forwards"])
     eng.run_steps(args.warmup)                       # W untimed warm-up steps
+    heartbeat("warm-up steps done")
     if args.prewarm_s > 0 and not args.plumbing_test:
         for ln in lanes:
             ln.prewarm(batch, 4)                     # keeps the GPU busy across the bookkeeping below (not waited for here)
@@ -436,8 +535,12 @@ def main():
         ln.sync()
     dist.barrier()
     dt_local = time.perf_counter() - t0
+    heartbeat("timed region done: %.3f s" % dt_local)
     dt = dist.all_reduce_max(dt_local)
     ranks_seen = int(round(dist.all_reduce_sum(1)))
+    if ranks_seen != world:
+        raise SystemExit("bench.py: the all-reduce saw %d ranks, WORLD_SIZE is %d" % (ranks_seen, world))
+    per_rank_rate = dist.all_gather_floats((eng.stats["leaf_evals"] - l0) / dt_local)     # a straggler is invisible under the MAX
     playouts = dist.all_reduce_sum(playouts_done() - p0)
     leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0)
     trunk_ms = trunk_cnt = fwd_ms = fwd_cnt = 0
@@ -491,6 +594,9 @@ def main():
                    "games_per_gpu": G, "leaf_batch": batch, "pipeline": args.pipeline, "host_threads": threads,
                    "mean_plies_per_game": mean_plies, "mean_plies_source": plies_src, "weights": "random init seed 0"},
         "ranks_seen": ranks_seen, "host_threads_per_rank": threads, "host_cpu_share": ncpu,
+        "per_rank_leaf_evals_per_s": per_rank_rate, "cpus_pinned_per_rank": pinned,
+        "warnings": (["host_threads_per_rank = %d < 3: the tree pool needs about three host threads per rank to keep one GPU "
+                      "busy (DESIGN section 5); this run is host-bound" % threads] if threads < 3 else []),
         "tree_arena_gb_per_rank": arena_gb,
         "launcher": "self-spawned" if os.environ.get("APZ_BENCH_SELF_SPAWNED") else
                     ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "single process"),
@@ -536,4 +642,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        if sys.exc_info()[0] is None:
+            dist.shutdown()

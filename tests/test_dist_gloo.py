@@ -96,10 +96,35 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launcher"] == "self-spawned"
     assert d["host_threads_per_rank"] == max(1, min(16, d["host_cpu_share"] // 2))
     assert d["tree_arena_gb_per_rank"] > 0 and d["valid"] is False
+    assert len(d["per_rank_leaf_evals_per_s"]) == 2 and all(x > 0 for x in d["per_rank_leaf_evals_per_s"])
+    assert isinstance(d["warnings"], list)
     # a rank that dies takes the whole command down with a non-zero exit code
     bad = subprocess.run(cmd, env=dict(env, APZ_BENCH_TEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=120)
     assert bad.returncode != 0 and "{" not in bad.stdout
+
+
+def test_bench_supervisor_deadlines():
+    """The self-spawning supervisor must not wait for ever: a rank that hangs before the rendezvous (the others then sit
+    in init_process_group), and a rank that leaves with exit code 0 while the others wait for it, both end in a
+    non-zero exit with every rank killed, within the configured deadlines."""
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--plumbing-test"]
+    t0 = time.time()
+    hung = subprocess.run(base + ["--rank-silence-s", "6"], env=dict(env, APZ_BENCH_TEST_HANG_RANK="1"),
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert hung.returncode != 0 and "{" not in hung.stdout and "no rank wrote to its log" in hung.stderr
+    assert time.time() - t0 < 120
+    t0 = time.time()
+    late = subprocess.run(base + ["--deadline-s", "5", "--rank-silence-s", "600"], env=dict(env, APZ_BENCH_TEST_HANG_RANK="1"),
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert late.returncode != 0 and "deadline" in late.stderr and time.time() - t0 < 120
+    early = subprocess.run(base + ["--early-exit-grace-s", "4"], env=dict(env, APZ_BENCH_TEST_EARLY_EXIT_RANK="1"),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert early.returncode != 0 and "exited 0 but the others are still running" in early.stderr
 
 
 def test_eight_rank_rehearsal(tmp_path):
