@@ -114,7 +114,7 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_layout_convert", "apz_bias_grad", "apz_add", "apz_load_weights_dev",
                "apz_sync", "apz_stream",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
-               "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms", "apz_prewarm"]
+               "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms", "apz_prewarm", "apz_test_select_trunk"]
 
 
 def _one_hip_runtime():
@@ -125,7 +125,7 @@ def _one_hip_runtime():
     memory and streams with torch, could then not run in a process that had evaluated first.  So: when torch is
     installed but not yet imported, map ITS runtime before ours (no `import torch`: that costs seconds)."""
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("APZ_NO_HIP_PRELOAD") == "1":     # opt-out switch
         return
     try:
         import importlib.util
@@ -135,8 +135,60 @@ def _one_hip_runtime():
     if spec is None or not spec.submodule_search_locations:
         return
     lib = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(lib):
-        C.CDLL(lib, mode=C.RTLD_GLOBAL)
+    if not os.path.exists(lib):
+        return
+    # Only a runtime of the SAME major version may stand in for the one libalphapig_hip.so was linked against: with
+    # different SONAMEs both would get mapped anyway (the failure this function exists to prevent), or the kernels would
+    # silently run on a runtime they were not built for.
+    want, have = _needed_hip_soname(HIP_LIB), _soname(lib)
+    if want and have and want != have:
+        import warnings
+        warnings.warn("torch bundles %s but %s needs %s: not preloading torch's HIP runtime (a later `import torch` in this "
+                      "process may not see the GPU)" % (have, os.path.basename(HIP_LIB), want))
+        return
+    C.CDLL(lib, mode=C.RTLD_GLOBAL)
+    if os.environ.get("APZ_LOG_HIP_RUNTIME") == "1":
+        print("[alphapig_amd] HIP runtime mapped from %s (%s)" % (lib, have), file=sys.stderr)
+
+
+def _dynamic_entries(path, tag):
+    """DT_* string entries (`tag`: 1 = NEEDED, 14 = SONAME) of an ELF64 shared object, parsed by hand (no binutils at run time)."""
+    import struct
+    out = []
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:4] != b"\x7fELF" or data[4] != 2:
+            return out
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        for sec in secs:
+            if sec[1] != 6:                                   # SHT_DYNAMIC
+                continue
+            strtab = secs[sec[6]]                             # sh_link -> .dynstr
+            for off in range(sec[4], sec[4] + sec[5], 16):
+                d_tag, d_val = struct.unpack_from("<qQ", data, off)
+                if d_tag == 0:
+                    break
+                if d_tag == tag:
+                    start = strtab[4] + d_val
+                    out.append(data[start:data.index(b"\0", start)].decode())
+    except (OSError, struct.error, ValueError, IndexError):
+        pass
+    return out
+
+
+def _soname(path):
+    e = _dynamic_entries(os.path.realpath(path), 14)
+    return e[0] if e else None
+
+
+def _needed_hip_soname(path):
+    for n in _dynamic_entries(path, 1):
+        if n.startswith("libamdhip64.so"):
+            return n
+    return None
 
 
 def hip():
@@ -207,6 +259,7 @@ def hip():
         "apz_set_profiling": (C.c_int, [vp, C.c_int]),
         "apz_kernel_time_ms": (C.c_int, [vp, C.c_int, f32p]),
         "apz_prewarm": (C.c_int, [vp, C.c_int, C.c_int]),
+        "apz_test_select_trunk": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

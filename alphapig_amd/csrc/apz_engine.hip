@@ -17,10 +17,7 @@
 #include "conv3x3_mfma.h"
 #include "heads.h"
 #include "trunk15_ring.h"
-#include "trunk15_wino.h"
-#include "trunk15_wino2.h"
 #include "trunk15_wino3.h"
-#include "wgrad_wino.h"
 #include "wgrad_wino2.h"
 #include "sampler.h"
 #include "conv_train.h"
@@ -60,8 +57,7 @@ struct ConvLayer {
     int cin, cin_pad, cout;
     bool residual;          // add the block input before ReLU
     float* wpk = nullptr;
-    float* upk = nullptr;   // trunk15_wino_kernel: transformed weights G g G^T in MFMA fragment order
-    float* upk2 = nullptr;  // trunk15_wino2_kernel: the same values, [cot][pass][c4][lane][20]
+    float* upk2 = nullptr;  // trunk15_wino3_kernel: transformed weights G g G^T, [cot][row half][c4][lane][20] (wino_common.h)
     float* bias = nullptr;
 };
 
@@ -128,9 +124,9 @@ struct apz_engine {
     float* wino_scratch[2] = {nullptr, nullptr};   // apz_wino_conv: rows16 input / output copies
     size_t wino_scratch_boards = 0;
     bool wgrad_attr_set[2] = {false, false};
-    int trunk_kernel = 3;   // 0: trunk15_ring_kernel (direct), 1: trunk15_wino_kernel, 2: trunk15_wino2_kernel,
-                            // 3: trunk15_wino3_kernel (APZ_TRUNK_KERNEL=ring|wino|wino2|wino3)
-    int trunk_waves = 4;    // waves per workgroup of trunk15_ring_kernel (APZ_TRUNK_WAVES=8 to try 2/SIMD)
+    hipStream_t scratch_stream = nullptr;          // the stream of the last entry point that may have used the scratch buffers
+    bool scratch_stream_valid = false;
+    int trunk_kernel = APZ_TRUNK_WINOGRAD;   // or APZ_TRUNK_DIRECT (trunk15_ring_kernel): apz_test_select_trunk, tests only
     // profiling
     bool profiling = false;
     int prof_stride = 1, prof_phase = 0;   // time every prof_stride-th forward only
@@ -350,76 +346,41 @@ int launch_trunk_ring_t(apz_engine* e, const ConvLayer& L, const float* in, cons
     return APZ_OK;
 }
 
-int launch_trunk_wino(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    using T = apz::Wino15;
-    bool& configured = e->lds_attr_set[4];
-    if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino_kernel<true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino_kernel<false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        configured = true;
-    }
-    const int grid = std::min(n, e->num_cu);   // one persistent workgroup per CU (register- and LDS-bound)
-    if (resid)
-        hipLaunchKernelGGL((apz::trunk15_wino_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk,
-                           L.bias, resid, out, n);
-    else
-        hipLaunchKernelGGL((apz::trunk15_wino_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk,
-                           L.bias, resid, out, n);
-    HIP_TRY(hipGetLastError());
-    return APZ_OK;
-}
+// trunk15_wino3_kernel addresses a launch's activations through 32-bit buffer offsets (and parks out-of-range lanes at
+// offset 2^31), so one launch takes at most WINO3_MAX_BOARDS boards; larger batches go out as several launches on
+// offset pointers -- a board's bits do not depend on the launch shape (tests/test_gpu_net.py).
+constexpr int WINO3_MAX_BOARDS = 16384;   // even (board pairs), 16384 * 128 planes * 960 B = 2^31 - 2^27
+static_assert((long long)WINO3_MAX_BOARDS * 128 * 960 < (1ll << 31), "wino3 buffer offsets");
 
-int launch_trunk_wino2(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    using T = apz::Wino2;
-    bool& configured = e->lds_attr_set[5];
+template <bool RESID, bool RELU>
+int launch_wino3_t(apz_engine* e, int attr_slot, const float* in, const float* upk, const float* bias, const float* resid,
+                   float* out, int n) {
+    using T = apz::Wino3;
+    bool& configured = e->lds_attr_set[attr_slot];
     if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<false>,
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<RESID, RELU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         configured = true;
     }
-    const int grid = std::min((n + 1) / 2, e->num_cu);   // one persistent workgroup per CU, a pair of boards at a time
-    if (resid)
-        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n);
-    else
-        hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n);
+    for (int b0 = 0; b0 < n; b0 += WINO3_MAX_BOARDS) {
+        const int nb = std::min(n - b0, WINO3_MAX_BOARDS);
+        const size_t off = (size_t)b0 * T::C * T::GPLANE;
+        const int grid = apz::wino3_grid(nb, e->num_cu);      // persistent workgroups; item = board pair x channel half
+        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<RESID, RELU>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in + off,
+                           upk, bias, RESID ? resid + off : nullptr, out + off, nb);
+    }
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
 
 int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    using T = apz::Wino3;
-    bool& configured = e->lds_attr_set[6];
-    if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        configured = true;
-    }
-    const int grid = apz::wino3_grid(n, e->num_cu);      // persistent workgroups; item = board pair x channel half
-    if (resid)
-        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n);
-    else
-        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in, L.upk2,
-                           L.bias, resid, out, n);
-    HIP_TRY(hipGetLastError());
-    return APZ_OK;
+    if (resid) return launch_wino3_t<true, true>(e, 6, in, L.upk2, L.bias, resid, out, n);
+    return launch_wino3_t<false, true>(e, 7, in, L.upk2, L.bias, nullptr, out, n);
 }
 
 int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    // wino3 addresses activations through 32-bit buffer offsets: n * 128 planes * 960 B must stay below 2^31
-    if (e->trunk_kernel == 3 && L.upk2 && (long long)n * 128 * 960 < (1ll << 31)) return launch_trunk_wino3(e, L, in, resid, out, n);
-    if (e->trunk_kernel >= 2 && L.upk2) return launch_trunk_wino2(e, L, in, resid, out, n);
-    if (e->trunk_kernel == 1 && L.upk) return launch_trunk_wino(e, L, in, resid, out, n);
-    if (e->trunk_waves == 8) return launch_trunk_ring_t<8>(e, L, in, resid, out, n);
-    return launch_trunk_ring_t<4>(e, L, in, resid, out, n);
+    if (e->trunk_kernel == APZ_TRUNK_WINOGRAD && L.upk2) return launch_trunk_wino3(e, L, in, resid, out, n);
+    return launch_trunk_ring_t<4>(e, L, in, resid, out, n);   // the direct convolution: in-tree cross-check of the Winograd kernel
 }
 
 template <int C4, int CIN, bool CODES>
@@ -611,7 +572,6 @@ void apz_destroy(apz_engine* e) {
     for (auto ev : e->free_events) hipEventDestroy(ev);
     for (auto& l : e->convs) {
         if (l.wpk) hipFree(l.wpk);
-        if (l.upk) hipFree(l.upk);
         if (l.upk2) hipFree(l.upk2);
         if (l.bias) hipFree(l.bias);
     }
@@ -678,9 +638,6 @@ apz_engine* apz_create(const apz_config* cfg) {
     if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", err);
     e->ring = cfg->net_kind == APZ_NET_RESNET && cfg->height == 15 && cfg->width == 15 && cfg->n_filter == 128;
-    if (const char* tk = getenv("APZ_TRUNK_KERNEL"))
-        e->trunk_kernel = std::string(tk) == "ring" ? 0 : std::string(tk) == "wino" ? 1 : std::string(tk) == "wino2" ? 2 : 3;
-    if (const char* tw = getenv("APZ_TRUNK_WAVES")) e->trunk_waves = (atoi(tw) == 8) ? 8 : 4;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
     const size_t B = cfg->max_batch, hw = e->hw;
@@ -771,13 +728,12 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
         rc = upload(&L.bias, bias);
         if (rc) return rc;
         if (x4) {
-            // F(4x4,3x3) Winograd weights U[pos = 6i+k][co][ci] = (G g G^T)[i][k] of the BN-folded
-            // kernel g, in double, rounded once; packed [cot 8][chunk 8][pos 36][lane 64][4]
-            // (trunk15_wino.h).
+            // F(4x4,3x3) Winograd weights U[pos = 6i+k][co][ci] = (G g G^T)[i][k] of the BN-folded kernel g, in double,
+            // rounded once; packed [cot 8][row half 2][c4 32][lane 64][20] (wino_common.h)
             static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6},
                                            {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
                                            {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-            std::vector<float> up(apz::Wino15::UPK_FLOATS), up2(apz::Wino2::UPK_FLOATS, 0.f);
+            std::vector<float> up2(apz::WinoPack::UPK_FLOATS, 0.f);
             for (int co = 0; co < 128; co++)
                 for (int ci = 0; ci < 128; ci++) {
                     double g[3][3], t[6][3];
@@ -785,19 +741,14 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
                         for (int b = 0; b < 3; b++) g[a][b] = (double)w[((size_t)co * 128 + ci) * 9 + a * 3 + b] * scale[co];
                     for (int i = 0; i < 6; i++)
                         for (int b = 0; b < 3; b++) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
-                    const int cot = co >> 4, jj = co & 15;
-                    const int chunk = ci >> 4, s4 = (ci & 15) >> 2, qq = ci & 3;
+                    const int cot = co >> 4, jj = co & 15, qq = ci & 3, c4 = ci >> 2;
                     for (int i = 0; i < 6; i++)
                         for (int k = 0; k < 6; k++) {
                             const double u = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
-                            const size_t idx = ((((size_t)cot * 8 + chunk) * 36 + (i * 6 + k)) * 64 + (qq * 16 + jj)) * 4 + s4;
-                            up[idx] = (float)u;
-                            const int pass = i / 3, c4 = ci >> 2;
-                            up2[((((size_t)cot * 2 + pass) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * pass) * 6 + k] = (float)u;
+                            const int half = i / 3;
+                            up2[((((size_t)cot * 2 + half) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * half) * 6 + k] = (float)u;
                         }
                 }
-            rc = upload(&L.upk, up);
-            if (rc) return rc;
             rc = upload(&L.upk2, up2);
             if (rc) return rc;
         }
@@ -1055,6 +1006,16 @@ struct StreamScope {      // run the engine's launch helpers on a caller-supplie
     hipStream_t saved;
     StreamScope(apz_engine* e_, void* s) : e(e_), saved(e_->stream) {
         if (s != APZ_ENGINE_STREAM) e->stream = (hipStream_t)s;   // NULL is a valid handle: the null stream
+        // The training entry points share per-engine scratch (head_scratch, bn_sums, fold_ws, wgw_scratch, wino_scratch,
+        // adam_tab).  Calls on ONE stream are ordered by the stream; a caller that switches streams gets the new stream
+        // ordered behind everything queued on the previous one, so two streams never work on the scratch at once.
+        if (e->scratch_stream_valid && e->scratch_stream != e->stream) {
+            hipEvent_t ev = get_event(e);
+            if (hipEventRecord(ev, e->scratch_stream) == hipSuccess) hipStreamWaitEvent(e->stream, ev, 0);
+            e->free_events.push_back(ev);
+        }
+        e->scratch_stream = e->stream;
+        e->scratch_stream_valid = true;
     }
     ~StreamScope() { e->stream = saved; }
 };
@@ -1081,17 +1042,32 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
             return fail(APZ_E_ARG, "parameter " + p.name + " has " + std::to_string(it->second) + " elements, expected " +
                                        std::to_string(p.size));
     }
+    // everything that can fail without having touched the weights comes first: shapes, scratch
+    for (auto& L : e->convs)
+        if (L.cout > 256) return fail(APZ_E_UNSUPPORTED, "load_weights_dev: more than 256 channels");
+    if (!e->fold_ws) HIP_TRY(hipMalloc((void**)&e->fold_ws, 2 * 256 * sizeof(double)));
     hipStream_t engine_stream = e->stream;
     {
         StreamScope sc(e, stream);
         hipStream_t st = e->stream;
-        if (!e->fold_ws) HIP_TRY(hipMalloc((void**)&e->fold_ws, 2 * 256 * sizeof(double)));
         if (st != engine_stream) {      // forwards already queued on the engine's stream still read the old weights
             hipEvent_t ev = get_event(e);
             HIP_TRY(hipEventRecord(ev, engine_stream));
             HIP_TRY(hipStreamWaitEvent(st, ev, 0));
             e->free_events.push_back(ev);
         }
+        // From here on packing kernels are queued on `st`: whatever happens below, the engine's stream must end up
+        // ordered behind them (a half-refreshed evaluator that ALSO races the packing kernels would be worse).
+        struct Closing {
+            apz_engine* e;
+            hipStream_t st, engine_stream;
+            ~Closing() {
+                if (st == engine_stream) return;
+                hipEvent_t ev = get_event(e);
+                if (hipEventRecord(ev, st) == hipSuccess) hipStreamWaitEvent(engine_stream, ev, 0);
+                e->free_events.push_back(ev);
+            }
+        } closing{e, st, engine_stream};
         double* scale = e->fold_ws;
         double* shift = e->fold_ws + 256;
         auto fold = [&](const std::string& conv, const std::string& bn, const std::string& mean_sfx, const std::string& var_sfx,
@@ -1101,7 +1077,6 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
                                P.at(bn + var_sfx), scale, shift, bias_out, cout, (double)BN_EPS);
         };
         for (auto& L : e->convs) {
-            if (L.cout > 256) return fail(APZ_E_UNSUPPORTED, "load_weights_dev: more than 256 channels");
             fold(L.name, L.bn, L.mean_sfx, L.var_sfx, L.fix_gamma, L.cout, L.bias);
             const float* w = P.at(L.name + "_weight");
             const int n4 = L.cin_pad / 4, ncot = L.cout / 16;
@@ -1110,7 +1085,8 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
             hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale, L.wpk,
                                L.cin, n4, ncot, (int)x4);
             if (x4)
-                hipLaunchKernelGGL(apz::pack_wino_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale, L.upk, L.upk2);
+                hipLaunchKernelGGL(apz::pack_wino_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale, L.upk2);
+            HIP_TRY(hipGetLastError());
         }
         const int C = e->clast, hw = e->hw;
         fold("conv3_1_1", "conv3_1_1", "_mean", "_var", true, 4, nullptr);
@@ -1126,12 +1102,7 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
         HIP_TRY(hipMemcpyAsync(e->bfc, P.at("fc_3_1_1_bias"), hw * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(e->wv, P.at("fc_3_2_1_weight"), 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(e->bv, P.at("fc_3_2_1_bias"), sizeof(float), hipMemcpyDeviceToDevice, st));
-        if (st != engine_stream) {      // forwards queued on the engine's stream from now on see the new weights
-            hipEvent_t ev = get_event(e);
-            HIP_TRY(hipEventRecord(ev, st));
-            HIP_TRY(hipStreamWaitEvent(engine_stream, ev, 0));
-            e->free_events.push_back(ev);
-        }
+        // (`closing` orders the engine's stream behind all of the above: forwards queued from now on see the new weights)
     }
     return APZ_OK;
 }
@@ -1190,7 +1161,7 @@ int apz_conv3x3_fwd(apz_engine* e, const void* x_dev, const void* wpk_dev, const
     return rc;
 }
 
-int64_t apz_wino_packed_size(void) { return (int64_t)apz::Wino2::UPK_FLOATS; }
+int64_t apz_wino_packed_size(void) { return (int64_t)apz::WinoPack::UPK_FLOATS; }
 
 int apz_wino_pack(apz_engine* e, const void* w_dev, int transpose_flip, void* upk_dev, void* stream) {
     if (!e || !w_dev || !upk_dev) return fail(APZ_E_ARG, "bad argument");
@@ -1234,33 +1205,13 @@ int apz_wino_conv_add(apz_engine* e, const void* x_dev, const void* upk_dev, con
                            e->wino_scratch[0], planes);
     const float* b = bias_dev ? (const float*)bias_dev : e->zeros256;
     const float* rs = (const float*)resid_dev;
-    // the self-play path's kernel (csrc/trunk15_wino3.h); it addresses activations through 32-bit buffer offsets, so
-    // batches of >= 2^31 / (128 * 960) boards take its predecessor
-    const bool k3 = (long long)n * 128 * 960 < (1ll << 31);
-    const int grid = k3 ? apz::wino3_grid(n, e->num_cu) : std::min((n + 1) / 2, e->num_cu);
-#define APZ_WINO_TRAIN(KERNEL, LDS, SLOT, RESID, RELU)                                                                       \
-    do {                                                                                                                     \
-        bool& configured = e->lds_attr_set[SLOT];                                                                            \
-        if (!configured) {                                                                                                   \
-            HIP_TRY(hipFuncSetAttribute((const void*)apz::KERNEL<RESID, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                        LDS));                                                                               \
-            configured = true;                                                                                               \
-        }                                                                                                                    \
-        hipLaunchKernelGGL((apz::KERNEL<RESID, RELU>), dim3(grid), dim3(512), LDS, e->stream, xin, (const float*)upk_dev, b, \
-                           rs, yout, n);                                                                                     \
-    } while (0)
-    if (k3) {
-        if (rs && relu) APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 16, true, true);
-        else if (rs) APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 17, true, false);
-        else if (relu) APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 18, false, true);
-        else APZ_WINO_TRAIN(trunk15_wino3_kernel, apz::Wino3::LDS_BYTES, 19, false, false);
-    } else {
-        if (rs && relu) APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 20, true, true);
-        else if (rs) APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 21, true, false);
-        else if (relu) APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 22, false, true);
-        else APZ_WINO_TRAIN(trunk15_wino2_kernel, apz::Wino2::LDS_BYTES, 23, false, false);
-    }
-#undef APZ_WINO_TRAIN
+    // the self-play path's kernel (csrc/trunk15_wino3.h)
+    int rc;
+    if (rs && relu) rc = launch_wino3_t<true, true>(e, 6, xin, (const float*)upk_dev, b, rs, yout, n);
+    else if (rs) rc = launch_wino3_t<true, false>(e, 17, xin, (const float*)upk_dev, b, rs, yout, n);
+    else if (relu) rc = launch_wino3_t<false, true>(e, 7, xin, (const float*)upk_dev, b, nullptr, yout, n);
+    else rc = launch_wino3_t<false, false>(e, 19, xin, (const float*)upk_dev, b, nullptr, yout, n);
+    if (rc) return rc;
     if (dense)
         hipLaunchKernelGGL(apz::rows16_to_dense_kernel, dim3(cgrid), dim3(256), 0, e->stream, e->wino_scratch[1],
                            (float*)y_dev, planes);
@@ -1423,13 +1374,10 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    // Decomposition by channel blocks (csrc/wgrad_wino2.h: 8 blocks x slices = one workgroup per CU) unless
-    // APZ_WGRAD_KERNEL=1 asks for the one by position groups (12 groups x slices ~ two workgroups per CU); either way
-    // the workgroups of a slice sit on one XCD (see the kernels)
-    static const bool by_blocks = !(getenv("APZ_WGRAD_KERNEL") && atoi(getenv("APZ_WGRAD_KERNEL")) == 1);
+    // Decomposition by channel blocks (csrc/wgrad_wino2.h: 8 blocks x slices = one workgroup per CU); the workgroups of a
+    // slice sit on one XCD (see the kernel)
     using T2 = apz::WgradWino2;
-    const int spx = by_blocks ? std::max(1, std::min((n + 7) / 8, e->num_cu / (8 * T2::BLOCKS)))
-                              : std::max(1, std::min((n + 7) / 8, 2 * e->num_cu / (8 * T::GROUPS)));
+    const int spx = std::max(1, std::min((n + 7) / 8, e->num_cu / (8 * T2::BLOCKS)));
     const int slices = 8 * spx;
     if (slices > e->wgw_slices) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1438,25 +1386,14 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
         HIP_TRY(hipMalloc((void**)&e->wgw_scratch, (size_t)slices * T::SCRATCH_FLOATS_PER_SLICE * sizeof(float)));
         e->wgw_slices = slices;
     }
-    bool& attr = e->lds_attr_set[9];
-    if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T::LDS_BYTES));
-        attr = true;
+    bool& attr2 = e->lds_attr_set[10];
+    if (!attr2) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T2::LDS_BYTES));
+        attr2 = true;
     }
-    if (by_blocks) {
-        bool& attr2 = e->lds_attr_set[10];
-        if (!attr2) {
-            HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        T2::LDS_BYTES));
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(apz::wgrad_wino2_kernel, dim3(T2::BLOCKS * slices), dim3(T2::THREADS), T2::LDS_BYTES, e->stream,
-                           (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
-    } else {
-        hipLaunchKernelGGL(apz::wgrad_wino_kernel, dim3(T::GROUPS * slices), dim3(T::THREADS), T::LDS_BYTES, e->stream,
-                           (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
-    }
+    hipLaunchKernelGGL(apz::wgrad_wino2_kernel, dim3(T2::BLOCKS * slices), dim3(T2::THREADS), T2::LDS_BYTES, e->stream,
+                       (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
     hipLaunchKernelGGL(apz::wgrad_wino_sum_kernel, dim3(36 * 128 * 128 / 4 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
                        slices);
     hipLaunchKernelGGL(apz::wgrad_wino_reduce_kernel, dim3(128 * 128 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
@@ -1792,6 +1729,14 @@ int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
     for (size_t pc = 0; pc < (size_t)e->last_n * C; pc++)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) host_out[(pc * H + y) * W + x] = tmp[pc * e->act_ps + y * e->act_rs + x];
+    return APZ_OK;
+}
+
+int apz_test_select_trunk(apz_engine* e, int kind) {
+    if (!e || (kind != APZ_TRUNK_WINOGRAD && kind != APZ_TRUNK_DIRECT)) return fail(APZ_E_ARG, "bad trunk kernel kind");
+    EngineLock guard(e->submit_lock);
+    if (!e->ring) return fail(APZ_E_UNSUPPORTED, "only the 15x15 / 128-filter residual net has two trunk kernels");
+    e->trunk_kernel = kind;
     return APZ_OK;
 }
 

@@ -52,8 +52,8 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
-// w [128][128][3][3] -> the transformed weights of trunk15_wino2_kernel, U = G g G^T in fp32:
-// [cot 8][pass 2][c4 32][lane 64][20] (trunk15_wino2.h).  One thread per (cot, pass, c4, lane): 18 values,
+// w [128][128][3][3] -> the transformed weights of trunk15_wino3_kernel, U = G g G^T in fp32:
+// [cot 8][row half 2][c4 32][lane 64][20] (wino_common.h).  One thread per (cot, pass, c4, lane): 18 values,
 // 80 contiguous bytes.  transpose_flip: the weights of the data-gradient convolution (see above).
 __global__ void pack_wino2_kernel(const float* __restrict__ w, float* __restrict__ upk, int transpose_flip) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

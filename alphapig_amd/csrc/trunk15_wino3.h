@@ -1,10 +1,10 @@
 // Trunk 3x3 convolution (128 -> 128 channels, 15x15 board) + folded BN + (residual) + ReLU as a
 // fused F(4x4,3x3) Winograd convolution on the fp32 matrix cores -- SINGLE PASS: a work item is
 // two boards x 64 output channels with all 36 transformed positions.  gfx950 only.
-// Successor of trunk15_wino2.h (same math, same HBM layouts, same packed weights `upk2`).
+// Successor of round 1's two-pass kernel (same math, same HBM layouts, same packed weights; git history / DESIGN section 4).
 //
-// Why (round-2 measurements of trunk15_wino2_kernel, profiles/r01_trunk_winograd.md): two boards x 128
-// channels x 36 positions of accumulators (590 KB) do not fit the 512 KB register file, so wino2 made
+// Why (measurements of that kernel, profiles/r01_trunk_winograd.md): two boards x 128
+// channels x 36 positions of accumulators (590 KB) do not fit the 512 KB register file, so round 1 made
 // two passes over the input (18 positions each), parked pass 0's partial outputs in `out` and re-read
 // them: 2.5x the direct-convolution HBM/fabric traffic, two epilogues (25 % of the launch) and an
 // input transform run by one wave per SIMD against the other's MFMA stream (16 %).
@@ -12,7 +12,7 @@
 // (295 KB) -- a weight fragment still feeds two MFMAs, nothing is parked, every output is written
 // once, the input is read once per channel half (2x, as before), and all eight waves do the same
 // thing in every chunk.  Price: the input transform runs once per channel half (2x the VALU work of
-// wino2); it is spread over all 512 threads (half a 6x6 tile each) and sits inside each wave's own
+// the two-pass kernel); it is spread over all 512 threads (half a 6x6 tile each) and sits inside each wave's own
 // MFMA stream, where a VALU instruction costs ~4 cycles instead of one MFMA slot (tools/mfma_valu_probe).
 //
 // Work item of a workgroup = (board pair, channel half h) (mapping: see the kernel).  Wave w: ct = w&3 (16 output
@@ -25,12 +25,12 @@
 // Epilogue of an item: wave (ct, ph) holds rows 3ph..3ph+2 of M; Y = A^T M A needs all six, so the
 // two waves of a channel tile swap 12 values per (channel, tile) through LDS (X) -- wave ph sends its
 // row-partial of board 1-ph and finishes board ph: + bias (+ residual), ReLU, whole-plane stores
-// through the wave-private staging area (as wino2).
+// through the wave-private staging area.
 //
 // Layouts.  in / resid / out: rows16 [n][128][15][16] (col 15 == 0), as trunk15_ring.h.
-// upk: [cot 8][ph 2][c4 32][lane 64][20] (Wino2's): lane (q = lane>>4, j = lane&15) holds
+// upk: [cot 8][ph 2][c4 32][lane 64][20] (wino_common.h): lane (q = lane>>4, j = lane&15) holds
 //      U[row 3*ph + ii][k] at index 6*ii + k of co = cot*16 + j, ci = c4*4 + q.
-// raw (LDS): as wino2 ([2 boards x 8 channels] planes, row stride 20, plane stride 340, zero halo).
+// raw (LDS): [2 boards x 8 channels] planes, row stride 20, plane stride 340, zero halo.
 // V (LDS): [pp 18][board 2][ch 8][tile 16][2]: pp = position pair (row i, columns 2kp, 2kp+1) = 3i + kp;
 //      the B operands of positions 2pp, 2pp+1 are one conflict-free ds_read_b64, no padding.
 // X (LDS, inside V[1], which is idle during an epilogue): [wave 8][12 values][lane 64].
@@ -39,7 +39,7 @@
 
 #include <type_traits>
 
-#include "trunk15_wino2.h"
+#include "wino_common.h"
 
 namespace apz {
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, T::C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_u =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(upk), 0, (unsigned)(Wino2::UPK_FLOATS * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(upk), 0, (unsigned)(WinoPack::UPK_FLOATS * 4), 0x00020000);
     auto bload = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     //   slices 3..7: B^T over the rows (elementwise in the columns), 18 packed operations:
     //                ph 0: y0 = 4x0 - 5x2 + x4, y1 = a + b, y2 = a - b with a = x4 - 4x2, b = x3 - 4x1   (x = patch rows 0..4)
     //                ph 1: y3 = c + 2d, y4 = c - 2d with c = z3 - z1, d = z2 - z0, y5 = 4z0 - 5z2 + z4  (z = patch rows 1..5)
-    //   slices 8..16: B^T over the columns of each of the three rows (wino2_bt6's formulas), three slices per row,
+    //   slices 8..16: B^T over the columns of each of the three rows (y0 = 4x0 - 5x2 + x4, y1/y2 = (x4 - 4x2) +- (x3 - 4x1), y3/y4 = (x4 - x2) +- 2(x3 - x1), y5 = 4x1 - 5x3 + x5), three slices per row,
     //                the row's three ds_write_b64 in its last slice.
     f32x2 xr[5][3], u0[3], u1[3], u2[3], tt[3][3];
     float o14[4];
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         }
 
         // ---- epilogue of the item.  Lane (q, j): tile j = 4*ety + etx, channels cot*16 + 4q + r.
-        // h_i = the k-direction transform of row i (wino2_at6).  With lo = (h0+h1+h2, h1-h2, h1+h2) from the ph = 0
+        // h_i = the k-direction transform A^T of row i (o0 = m0+m1+m2+m3+m4, o1 = (m1-m2) + 2(m3-m4), o2 = (m1+m2) + 4(m3+m4), o3 = (m1-m2) + 8(m3-m4) + m5).  With lo = (h0+h1+h2, h1-h2, h1+h2) from the ph = 0
         // wave and hi = (h3+h4, h3-h4, h5) from the ph = 1 wave:
         //   y0 = lo0 + hi0;  y1 = lo1 + 2 hi1;  y2 = lo2 + 4 hi0;  y3 = lo1 + 8 hi1 + hi2.
         // Wave ph finishes board ph and sends its partial of board 1-ph.  No divergence: every wave runs the same
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
             return (unsigned)__builtin_amdgcn_readfirstlane(bd_own * T::C + cot * 16 + qp * 4 + r) * plane_b;
         };
         // rows of this wave -> (P0, P1, P2) for TWO channels at once: components r0, r0 + 1 of an accumulator are
-        // neighbouring registers, so the whole k-direction transform (wino2_at6's formulas) and the row sums run as
+        // neighbouring registers, so the whole k-direction transform (the formulas above) and the row sums run as
         // packed two-wide operations -- half the VALU instructions of the epilogue's biggest part
         auto partial2 = [&](const f32x4* a, auto R0, f32x2 (*p)[4]) {
             constexpr int r0 = decltype(R0)::value;

@@ -39,10 +39,9 @@ __global__ void pack_direct_kernel(const float* __restrict__ w, const double* __
 }
 
 // F(4x4,3x3) Winograd weights of the 128 -> 128 trunk shape, U[6i+k][co][ci] = (G g G^T)[i][k] of the folded kernel, in
-// double, rounded once; both packed layouts (trunk15_wino.h: [cot 8][chunk 8][pos 36][lane 64][4]; trunk15_wino2.h /
-// wino3.h: [cot 8][row half 2][c4 32][lane 64][20]).  One thread per (co, ci).
-__global__ void pack_wino_folded_kernel(const float* __restrict__ w, const double* __restrict__ scale, float* __restrict__ up,
-                                        float* __restrict__ up2) {
+// double, rounded once, in trunk15_wino3.h's layout (wino_common.h: [cot 8][row half 2][c4 32][lane 64][20]).  One thread
+// per (co, ci).
+__global__ void pack_wino_folded_kernel(const float* __restrict__ w, const double* __restrict__ scale, float* __restrict__ up2) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 128 * 128) return;
     const int co = idx >> 7, ci = idx & 127;
@@ -58,13 +57,12 @@ __global__ void pack_wino_folded_kernel(const float* __restrict__ w, const doubl
 #pragma unroll
         for (int b = 0; b < 3; b++) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
     const int cot = co >> 4, jj = co & 15;
-    const int chunk = ci >> 4, s4 = (ci & 15) >> 2, qq = ci & 3, c4 = ci >> 2;
+    const int qq = ci & 3, c4 = ci >> 2;
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const double u = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
-            up[((((size_t)cot * 8 + chunk) * 36 + (i * 6 + k)) * 64 + (qq * 16 + jj)) * 4 + s4] = (float)u;
             const int pass = i / 3;
             up2[((((size_t)cot * 2 + pass) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * pass) * 6 + k] = (float)u;
         }

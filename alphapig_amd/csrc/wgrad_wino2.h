@@ -1,10 +1,14 @@
 // Weight gradient of the trunk convolution (128 -> 128, 15x15) through the Winograd F(4x4,3x3) domain, decomposed by
-// CHANNEL BLOCKS.  gfx950.  Same mathematics and same scratch layout as wgrad_wino.h (its sum / reduce kernels finish
-// the job); what changes is who does what:
+// CHANNEL BLOCKS.  gfx950.
 //
-//   dU[pos][co][ci] = sum over boards and tiles of dM[pos][co][tile] * V[pos][ci][tile],  dM = A dY A^T,  V = B^T d B.
+// Forward (trunk15_wino3.h): Y = A^T [ sum_ci U (.) V ] A with U = G g G^T, V = B^T d B.  Hence
+//   dU[pos][co][ci] = sum over boards and tiles of dM[pos][co][tile] * V[pos][ci][tile],  dM = A dY A^T (6x6 from 4x4),
+//   dg[co][ci]      = G^T dU G                                                             (3x3 from 6x6)
+// i.e. 36 independent [128 x K] x [K x 128] products with K = 16 tiles per board: 9 216 fp32 MFMAs per board instead of the
+// 32 832 of the direct form (conv3x3_wgrad_kernel).  Partial dU of the batch slices go to a scratch tensor;
+// wgrad_wino_sum_kernel / wgrad_wino_reduce_kernel (below) add them and apply G^T . G.
 //
-// wgrad_wino_kernel gives a workgroup three of the 36 positions and all 128 x 128 channel pairs: every board's 256
+// Round 2's first version (by position groups, in the git history) gave a workgroup three of the 36 positions and all 128 x 128 channel pairs: every board's 256
 // planes are read by twelve workgroups (2.9 MB of L2 -> CU traffic per board, 1.5 GB per 512-board launch), and each of
 // them repeats the first transform stage of every (plane, tile) for its own position row (3 220 VALU instructions per
 // workgroup and board against 768 MFMAs).  Here a workgroup owns a block of 64 output x 32 input channels with ALL 36
@@ -28,7 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "wgrad_wino.h"
+#include "wino_common.h"
 
 #ifndef APZ_WGW2_NO_TRANSFORM
 #define APZ_WGW2_NO_TRANSFORM 0   /* measurement builds: skip the transforms / the MFMA phase */
@@ -52,6 +56,37 @@ struct WgradWino2 {
     static constexpr int THREADS = 512;
 };
 static_assert(WgradWino2::LDS_BYTES <= 160 * 1024, "LDS");
+
+// partial dU of one batch slice: [36][128 co][128 ci]
+struct WgradWino {
+    static constexpr size_t SCRATCH_FLOATS_PER_SLICE = (size_t)36 * 128 * 128;
+};
+
+// rows of B^T (6x6) and of A (6x4): the workgroup's position row is a runtime value, so the first transform stage is
+// a plain coefficient dot product (a `switch` on the row made hipcc evaluate every case and select)
+__device__ const float WGW_BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                       {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+__device__ const float WGW_A[6][4] = {{1, 0, 0, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}, {1, 2, 4, 8}, {1, -2, 4, -8}, {0, 0, 0, 1}};
+
+// One wave-instruction of LDS-DMA: lane l copies 16 bytes from its global address to LDS byte lds_base + 16 l.
+// Inline assembly, so that hipcc's wait-count insertion does not see it (it would put vmcnt(0) in front of every LDS
+// read that might alias a DMA destination, i.e. wait for the chunk just requested); the kernel counts by hand.
+__device__ __forceinline__ void wgw_dma16(const float* gsrc_lane, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(lds_base) : "memory");
+}
+// ... and of 4 bytes per lane: pulls the 128-byte lines of a later chunk into this XCD's L2 (one lane per line); the
+// bytes land in a junk area of LDS, so no register waits for them
+__device__ __forceinline__ void wgw_touch(const float* gsrc_lane, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc_lane), "s"(lds_base) : "memory");
+}
+
+// lane k of every quad takes `v` of lane k-1 (DOWN) / k+1 (UP); the quad's ends get 0
+template <bool UP>
+__device__ __forceinline__ float wgw_quad_neighbour(float v, int k) {
+    const int moved = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), UP ? 0xf9 : 0x90, 0xf, 0xf, false);   // quad_perm [1,2,3,3] / [0,0,1,2]
+    return k == (UP ? 3 : 0) ? 0.f : __builtin_bit_cast(float, moved);
+}
+
 
 // x, dy: padded-row layout [n][128][15][16].  scratch: [slices][36][128 co][128 ci] (partial dU per batch slice).
 // Grid: 8 * BLOCKS * spx workgroups, slices = 8 * spx.  Workgroup L (dispatched round-robin over the XCDs, L mod 8 = its
@@ -291,6 +326,45 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
                 for (int r = 0; r < 4; r++)
                     out[((size_t)(pg * 9 + p) * T::C + cob * T::CO_B + (2 * cc + a) * 16 + 4 * q + r) * T::C + cib * T::CI_B +
                         b * 16 + j] = acc[p][a][b][r];
+}
+
+// stage 1: dU[pos][co][ci] = sum over slices (in place into slice 0); one thread per element, 16-byte accesses
+__global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(float* __restrict__ scratch, int slices) {
+    const long i = blockIdx.x * 256L + threadIdx.x;          // float4 index into [36][128][128]
+    if (i >= 36L * 128 * 128 / 4) return;
+    f32x4 a = reinterpret_cast<const f32x4*>(scratch)[i];
+    for (int s = 1; s < slices; s++) a += reinterpret_cast<const f32x4*>(scratch + (size_t)s * 36 * 128 * 128)[i];
+    reinterpret_cast<f32x4*>(scratch)[i] = a;
+}
+
+// stage 2: dw[co][ci][a][b] = sum_{i,k} G[i][a] G[k][b] dU[6i+k][co][ci]   (one thread per (co, ci))
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ du, float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // co * 128 + ci
+    if (idx >= 128 * 128) return;
+    const float G[6][3] = {{0.25f, 0.f, 0.f},           {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float u[36];
+#pragma unroll
+    for (int p = 0; p < 36; p++) u[p] = du[(size_t)p * (128 * 128) + idx];
+    float t[3][6];                                   // t[a][k] = sum_i G[i][a] dU[i][k]
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v += G[i][a] * u[i * 6 + k];
+            t[a][k] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; b2++) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += t[a][k] * G[k][b2];
+            dw[(size_t)idx * 9 + a * 3 + b2] = v;
+        }
 }
 
 }  // namespace apz

@@ -1,0 +1,33 @@
+// Shared pieces of the Winograd F(4x4,3x3) trunk kernels (trunk15_wino3.h, wgrad_wino2.h) for gfx950: vector types,
+// the packed FMA, the wavefront-scope LDS fence and the packed-weight geometry.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv3x3_mfma.h"
+
+namespace apz {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Transformed weights U = G g G^T of one 128 -> 128 layer, packed per MFMA A fragment:
+// [cot 8][row half 2][c4 32][lane 64][20] -- lane (q = lane>>4, j = lane&15) holds U[row 3*half + ii][k] at index
+// 6*ii + k of co = cot*16 + j, ci = c4*4 + q (18 values + 2 pad: four 16-byte loads + one 8-byte load per k-step).
+struct WinoPack {
+    static constexpr int UROW = 20;                    // floats per lane and k-step
+    static constexpr size_t UPK_FLOATS = (size_t)8 * 2 * 32 * 64 * UROW;   // per layer (2.6 MB)
+};
+
+__device__ __forceinline__ f32x2 fma2(const float a, const f32x2 b, const f32x2 c) {   // a*b + c (v_pk_fma_f32)
+    return __builtin_elementwise_fma(f32x2{a, a}, b, c);
+}
+
+// Lanes of ONE wave exchange data through LDS (write in one layout, read in another).  The LDS executes a
+// wave's instructions in order, so no s_barrier is needed -- but the compiler reasons per thread and may move
+// a lane's read above its own (provably different-address) write.  This pins the order for the compiler.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace apz

@@ -116,6 +116,61 @@ def all_gather_floats(x):
     return [float(v) for v in out.cpu()]
 
 
+def rank_world():
+    """(rank, world) of this process: from the live process group, else from the launcher's environment, else (0, 1)."""
+    if _ACTIVE:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def is_active():
+    """True once init() has created (or found) a process group with more than one rank, or was forced."""
+    return _ACTIVE
+
+
+def broadcast_params(params, src=0):
+    """The weight exchange after a training step (the reference re-syncs its predict modules from the train module,
+    policy_value_net_mxnet.py:295-297; across ranks that is one 12.7 MB broadcast): `params` is an ordered
+    {name: tensor or ndarray}; rank `src` sends its values, every rank returns {name: tensor} with the SAME names, shapes
+    and order holding src's values -- device tensors under RCCL (ready for PolicyValueNet.load_device_params), CPU tensors
+    under gloo.  All tensors travel as ONE flat float32 buffer (one collective, not one per tensor)."""
+    import torch
+    import torch.distributed as dist
+    names = list(params.keys())
+    if not (_ACTIVE and dist.is_initialized()):
+        return {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))) for k, v in params.items()}
+    dev = _device()
+    parts = []
+    for k in names:
+        v = params[k]
+        t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+        parts.append(t.detach().to(device=dev, dtype=torch.float32).reshape(-1))
+    flat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float32, device=dev)
+    dist.broadcast(flat, src=src)
+    out, off = {}, 0
+    for k, t in zip(names, parts):
+        n = t.numel()
+        v = params[k]
+        out[k] = flat[off:off + n].reshape(tuple(v.shape)).contiguous()
+        off += n
+    return out
+
+
+def broadcast_floats(values, src=0):
+    """A few Python floats from rank `src` to everybody (loss / KL / lr multiplier of a policy update, for the logs)."""
+    if not _ACTIVE:
+        return [float(v) for v in values]
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=_device())
+    dist.broadcast(t, src=src)
+    return [float(v) for v in t.cpu()]
+
+
 def all_gather_tuples(codes, pis, zs):
     """codes uint8 [T, S], pis float32 [T, HW], zs float32 [T] of this rank ->
     the concatenation over ranks in rank order (every rank gets everything).

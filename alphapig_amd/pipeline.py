@@ -16,6 +16,19 @@ is re-folded with the new weights and the engine's slots keep playing with them 
 were built under the previous weights -- like the reference's, whose tree is also reused across
 the update that happens between two games only at game boundaries; here the switch can fall
 inside a game).
+
+Multi-GPU (BASELINE configs[4]: "competition-strength self-play for the train_mxnet.py pipeline" on 8 GPUs):
+one process per GPU, `distributed=True` (default: on when alphapig_amd.dist holds a process group).  Per game batch
+    every rank   self-plays its shard of the global game sequence (rank r owns games r, r + R, ...) until
+                 `play_batch_size` of ITS games have finished, then joins ONE `dist.all_gather_tuples` of [codes | pi | z];
+    rank 0       expands the gathered tuples (rank-major order), augments them (get_equi_data) into THE replay buffer,
+                 runs `policy_update` (KL monitor and lr_multiplier live here only), saves / evaluates on schedule;
+    every rank   receives rank 0's verdict (`dist.broadcast_floats`: updated?, loss, entropy, kl, lr_multiplier) and, after
+                 an update, the new weights (`dist.broadcast_params`: one flat 12.7 MB RCCL broadcast, the cross-rank form of
+                 the reference's predict-module re-sync, policy_value_net_mxnet.py:295-297) -> `load_device_params`
+                 (device to device) and goes on playing with them.
+The reference has no multi-process collector (train_mxnet.py:182-191 is commented out); the loop is its `run`
+(train_mxnet.py:265-300) with collect -> all-gather -> update -> broadcast.
 """
 import logging
 import os
@@ -23,7 +36,7 @@ import random
 
 import numpy as np
 
-from . import sgf
+from . import dist, sgf
 from .arena import Arena, win_ratio
 from .augment import get_equi_data
 from .game import Board, Game
@@ -76,7 +89,16 @@ class ReplayBuffer(object):
 
 
 class TrainPipeline(object):
-    def __init__(self, conf, init_model=None, policy_value_net=None, device=0, seed=0):
+    def __init__(self, conf, init_model=None, policy_value_net=None, device=0, seed=0, distributed=None, trainer=None):
+        """policy_value_net: an evaluator to use instead of building the HIP PolicyValueNet (needs evaluate_codes, params /
+        set_params; policy_value for the KL monitor on rank 0).  trainer: an object with HipTrainer's interface
+        (train_step, get_params; optionally sync_evaluator) to use instead of creating a HipTrainer -- the CPU tests pass
+        stand-ins for both.  distributed: None = on iff alphapig_amd.dist holds a process group."""
+        self.distributed = dist.is_active() if distributed is None else bool(distributed)
+        self.rank, self.world = dist.rank_world() if self.distributed else (0, 1)
+        self._trainer_override = trainer
+        self._seed = seed
+        self._train_steps = 0
         self.board_width, self.board_height = conf["board_width"], conf["board_height"]
         self.n_in_row = conf["n_in_row"]
         self.learn_rate, self.lr_multiplier = conf["learn_rate"], conf.get("lr_multiplier", 1.0)
@@ -106,7 +128,9 @@ class TrainPipeline(object):
         self.engine = SelfPlayEngine(self.policy_value_net, self.board_width, self.board_height, self.n_in_row,
                                      n_games=concurrent, n_playout=self.n_playout, c_puct=self.c_puct,
                                      temp=self.temp, base_seed=seed, pipeline=2,
-                                     forced_opening=(self.board_width == 15 and self.board_height == 15))
+                                     forced_opening=(self.board_width == 15 and self.board_height == 15),
+                                     index_offset=self.rank, index_stride=self.world)
+        self.keep_replica_buffers = bool(conf.get("replica_buffers", False))    # every rank keeps the replay buffer (host RAM x world)
         self._taken = 0
         self._rng = random.Random(seed)
         self.episode_len = 0
@@ -114,14 +138,25 @@ class TrainPipeline(object):
 
     # ---- data collection -----------------------------------------------------------------
     def collect_selfplay_data_ai(self, n_games=1):
-        """train_mxnet.py:170-180, batched: take the next n finished games from the engine."""
+        """train_mxnet.py:170-180, batched: take the next n finished games from the engine (of THIS rank's shard; with
+        several ranks the batch is the rank-major concatenation of every rank's n games)."""
         while len(self.engine.finished) < n_games:           # completion order, like a game queue
             self.engine.run_steps(16)
         eps = self.engine.finished[:n_games]
         del self.engine.finished[:n_games]
         self._taken += n_games
         self.episode_len = int(np.mean([len(e.moves) for e in eps]))
-        states, pis, zs = episodes_to_tuples(eps, self.engine.pool)
+        if not self.distributed:
+            states, pis, zs = episodes_to_tuples(eps, self.engine.pool)
+        else:
+            codes = np.concatenate([e.codes for e in eps])
+            pis = np.concatenate([e.pis for e in eps]).astype(np.float32)
+            zs = np.concatenate([e.zs for e in eps]).astype(np.float32)
+            codes, pis, zs = dist.all_gather_tuples(codes, pis, zs)          # THE exchange of the round (RCCL all-gather)
+            self.last_gathered = len(zs)
+            if self.rank != 0 and not self.keep_replica_buffers:
+                return
+            states = self.engine.pool.codes_to_planes(codes, 9)
         self.data_buffer.extend(get_equi_data(list(zip(states, pis, zs)), self.board_height, self.board_width))
 
     def collect_selfplay_data(self, training_index):
@@ -136,19 +171,68 @@ class TrainPipeline(object):
         self.data_buffer.extend(get_equi_data(data, self.board_height, self.board_width))
 
     # ---- update / evaluation ---------------------------------------------------------------
-    def policy_update(self):
-        """train_mxnet.py:194-240."""
-        mini = self.data_buffer.sample(self._rng, self.batch_size)
+    def _trainer(self):
         net = self.policy_value_net
+        if self._trainer_override is not None:
+            return self._trainer_override
         from .train import HipTrainer
         if getattr(net, "_trainer", None) is None:
+            # a re-created trainer (set_params dropped the old one) continues the dropout mask sequence instead of replaying it
             net._trainer = HipTrainer(net.params(), net.net_kind, net._n_blocks, batch_size=self.batch_size,
-                                      device_index=net._device)
+                                      device_index=net._device, seed=self._seed, dropout_step0=self._train_steps)
+        return net._trainer
+
+    def policy_update(self):
+        """train_mxnet.py:194-240 (rank 0 of a multi-rank run; see `_exchange_update`)."""
+        mini = self.data_buffer.sample(self._rng, self.batch_size)
+        net = self.policy_value_net
+        trainer = self._trainer()
+        t_before = getattr(trainer, "t", 0)
         # the self-play evaluator itself supplies the old / new predictions of the KL monitor (re-folded per epoch)
-        loss, entropy, kl, self.lr_multiplier = policy_update(net._trainer, mini, self.learn_rate, self.lr_multiplier,
+        loss, entropy, kl, self.lr_multiplier = policy_update(trainer, mini, self.learn_rate, self.lr_multiplier,
                                                               self.epochs, self.kl_targ, evaluator=_KeepTrainer(net))
+        self._train_steps += max(0, getattr(trainer, "t", 0) - t_before)
         _logger.info("kl:%.4f lr_multiplier:%.3f loss:%.4f entropy:%.4f", kl, self.lr_multiplier, loss, entropy)
         return loss, entropy, kl
+
+    def _exchange_update(self, rec):
+        """The update step of one game batch across ranks: rank 0 decides and trains, everybody learns the outcome and, if
+        the weights changed, receives them (module docstring).  Single rank: just the update."""
+        do = self.rank == 0 and len(self.data_buffer) > self.batch_size
+        if not self.distributed:
+            if do:
+                rec["loss"], rec["entropy"], rec["kl"] = self.policy_update()
+            return
+        head = [0.0, 0.0, 0.0, 0.0, self.lr_multiplier]
+        if do:
+            loss, entropy, kl = self.policy_update()
+            head = [1.0, loss, entropy, kl, self.lr_multiplier]
+        head = dist.broadcast_floats(head, src=0)
+        if head[0] == 0.0:
+            return
+        rec["loss"], rec["entropy"], rec["kl"] = head[1], head[2], head[3]
+        rec["lr_multiplier"] = head[4]          # informational on ranks > 0: the adaptive state lives on rank 0
+        net = self.policy_value_net
+        if self.rank == 0:
+            tr = self._trainer()
+            src = tr.p if hasattr(tr, "p") else tr.get_params()
+        else:
+            src = self._param_template()
+        got = dist.broadcast_params({k: src[k] for k in sorted(src)}, src=0)
+        if self.rank != 0:
+            first = next(iter(got.values()))
+            if getattr(first, "is_cuda", False) and hasattr(net, "load_device_params"):
+                self._held = got                 # the evaluator packs from these tensors asynchronously: keep them alive
+                net.load_device_params(got)
+            else:
+                net.set_params({k: v.cpu().numpy() for k, v in got.items()})
+        self.weight_broadcasts = getattr(self, "weight_broadcasts", 0) + 1
+
+    def _param_template(self):
+        """Names and shapes of the parameter set (ranks > 0 never build a trainer; values are overwritten by the broadcast)."""
+        if getattr(self, "_template", None) is None:
+            self._template = {k: np.zeros(v.shape, np.float32) for k, v in self.policy_value_net.params().items()}
+        return self._template
 
     def policy_evaluate(self, n_games=None):
         """train_mxnet.py:242-263: win ratio of the current net against pure MCTS."""
@@ -158,19 +242,20 @@ class TrainPipeline(object):
         return win_ratio(res)
 
     def run(self):
-        """train_mxnet.py:265-300."""
+        """train_mxnet.py:265-300; with several ranks every rank runs this loop (module docstring)."""
+        lead = self.rank == 0
         for i in range(self.game_batch_num):
             if i < self.sgf_batches and self._training_data:
-                self.collect_selfplay_data(i)
+                if lead:                                    # game records are rank 0's: the other ranks keep playing
+                    self.collect_selfplay_data(i)
             else:
                 self.collect_selfplay_data_ai(self.play_batch_size)
             rec = {"batch": i + 1, "episode_len": self.episode_len, "buffer": len(self.data_buffer)}
-            if len(self.data_buffer) > self.batch_size:
-                rec["loss"], rec["entropy"], rec["kl"] = self.policy_update()
-            if (i + 1) % 50 == 0:
+            self._exchange_update(rec)
+            if lead and (i + 1) % 50 == 0:
                 os.makedirs(self.model_dir, exist_ok=True)
                 self.policy_value_net.save_model(os.path.join(self.model_dir, "current_policy.model"))
-            if (i + 1) % self.check_freq == 0:
+            if lead and (i + 1) % self.check_freq == 0:
                 rec["win_ratio"] = wr = self.policy_evaluate()
                 if wr > self.best_win_ratio:
                     self.best_win_ratio = wr

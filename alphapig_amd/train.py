@@ -35,7 +35,11 @@ SIMPLE_CONVS = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv_final")
 
 class HipTrainer(object):
     def __init__(self, params, net_kind="resnet", n_blocks=10, batch_size=512, wd=1e-4, device_index=0, dropout=0.5,
-                 seed=0):
+                 seed=0, height=None, width=None, dropout_step0=0):
+        """params: name -> array, in any order.  height / width: the board (default: square, from the policy head's size).
+        seed / dropout_step0: the dropout masks are a stateless hash of (seed, dropout_step0 + step, element) -- a trainer
+        that is re-created (set_params, a resumed checkpoint) or one of several ranks passes its own seed / the steps
+        already taken, or it replays the mask sequence of a fresh trainer."""
         import torch
         from . import _native, hipconv
         if not torch.cuda.is_available():
@@ -48,10 +52,19 @@ class HipTrainer(object):
         self.p = collections.OrderedDict()
         for k, v in params.items():
             self.p[k] = torch.tensor(np.ascontiguousarray(v, dtype=np.float32), device=self.device)
-        first = next(iter(self.p.values()))
-        self.c_in = int(first.shape[1])
+        stem = "res_conv1_weight" if net_kind == "resnet" else "conv1_weight"
+        if stem not in self.p:
+            raise ValueError("parameter %s missing (net_kind %r)" % (stem, net_kind))
+        self.c_in = int(self.p[stem].shape[1])
         self.hw = int(self.p["fc_3_1_1_bias"].shape[0])
         self.side = int(round(self.hw ** 0.5))
+        if (height is None) != (width is None):
+            raise ValueError("pass both height and width, or neither")
+        if height is not None and (int(height) * int(width) != self.hw or int(height) != int(width)):
+            raise ValueError("the HIP training kernels take square boards whose size matches the policy head (%d cells)" % self.hw)
+        if self.side * self.side != self.hw:
+            raise ValueError("policy head of %d cells is not a square board" % self.hw)
+        self.dropout_step0 = int(dropout_step0)
         self.stat_names = [k for k in self.p if k.endswith(("_mean", "_var", "_moving_mean", "_moving_var"))]
         # gammas of the fix_gamma BatchNorm layers (every conv_act layer: res_conv1, the two 1x1 heads, and all of the
         # simple net; policy_value_loss.json nodes 9 / 208 / 226 carry no fix_gamma=False) never enter the graph.
@@ -132,8 +145,8 @@ class HipTrainer(object):
         pol, val = pol.view(n, -1), val.view(n, -1)
         if self.dropout > 0:
             keep = 1.0 - self.dropout
-            pol = o.dropout(pol, keep, self.seed, 2 * step)
-            val = o.dropout(val, keep, self.seed, 2 * step + 1)
+            pol = o.dropout(pol, keep, self.seed, 2 * (self.dropout_step0 + step))
+            val = o.dropout(val, keep, self.seed, 2 * (self.dropout_step0 + step) + 1)
         tape["pol_in"], tape["val_in"] = pol, val
         logits = o.fc_fwd(pol, p["fc_3_1_1_weight"], p["fc_3_1_1_bias"])
         vlogit = o.fc_fwd(val, p["fc_3_2_1_weight"], p["fc_3_2_1_bias"]).view(n)
@@ -148,8 +161,8 @@ class HipTrainer(object):
         dval, g["fc_3_2_1_weight"], g["fc_3_2_1_bias"] = o.fc_bwd(tape["val_in"], p["fc_3_2_1_weight"], dvlogit.view(n, 1))
         if self.dropout > 0:
             keep = 1.0 - self.dropout
-            dpol = o.dropout(dpol, keep, self.seed, 2 * tape["step"])
-            dval = o.dropout(dval, keep, self.seed, 2 * tape["step"] + 1)
+            dpol = o.dropout(dpol, keep, self.seed, 2 * (self.dropout_step0 + tape["step"]))
+            dval = o.dropout(dval, keep, self.seed, 2 * (self.dropout_step0 + tape["step"]) + 1)
         dx = self._conv_act_bwd(dpol.view(n, 4, self.side, self.side), tape["pol"], True)
         dx = self._conv_act_bwd(dval.view(n, 2, self.side, self.side), tape["val"], True, dx_acc=dx)
         if self.kind == "resnet":

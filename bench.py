@@ -81,7 +81,7 @@ def _cpu_worker(budget_s):
     from oracle.mcts_ref import RefMCTS
     from oracle.net_ref_c import CNet
     prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
-    net = CNet(prm, H, W, 9, N_FILTER, N_BLOCKS)
+    net = CNet(prm, H, W, 9, N_FILTER, N_BLOCKS, fast=True)    # the vectorised forward (checked against the plain loops in tests/test_oracle_net.py)
     b = RefBoard(W, H, N_IN_ROW)
     b.init_board()
     mcts = RefMCTS(net.policy_value_fn, c_puct=5, n_playout=N_PLAYOUT)
@@ -558,9 +558,7 @@ def main():
 
     games_per_s = playouts / N_PLAYOUT / mean_plies / dt
     st_ms = sorted(1e3 * x for x in getattr(eng, "step_times", []))
-    # which trunk kernel ran (apz_engine.hip reads the same variable; default = the single-pass Winograd pair kernel)
-    tk = os.environ.get("APZ_TRUNK_KERNEL", "wino3")
-    tk = tk if tk in ("ring", "wino", "wino2") else "wino3"
+    tk = "wino3"                                    # the product's trunk kernel (csrc/trunk15_wino3.h)
     # HBM / fabric traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
     # (cannot be collected from inside the process), committed under profiles/
     traffic, traffic_src = None, None
@@ -573,15 +571,12 @@ def main():
                 traffic, traffic_src = tj["traffic_bytes_per_launch"]["mean"], "profiles/" + tname
                 break
     trunk_avg_ms = trunk_ms / max(trunk_cnt, 1)
-    kernel_name = {"ring": "trunk15_ring_kernel<RESID,4> (direct 3x3 convolution on fp32 MFMA)",
-                   "wino": "trunk15_wino_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, one board per workgroup)",
-                   "wino2": "trunk15_wino2_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, two boards per workgroup, two position passes)",
-                   "wino3": "trunk15_wino3_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, single pass: two boards x 64 output channels per work item)"}[tk]
-    # MFMA flops the kernel really issues: direct = the algorithmic count on 16-wide rows; Winograd =
-    # 36 positions x 8 channel tiles x 32 k-steps of v_mfma_f32_16x16x4_f32 (2048 flop) per board.
+    kernel_name = "trunk15_wino3_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, single pass: two boards x 64 output channels per work item)"
+    # MFMA flops the kernel really issues: 36 positions x 8 channel tiles x 32 k-steps of v_mfma_f32_16x16x4_f32
+    # (2048 flop) per board.
     # `achieved` / `frac` are on THIS basis (a fraction of the matrix pipe's peak, <= 1); the rate of the layer's
     # definition (direct-convolution flops / time, which Winograd makes exceed the peak) is kept beside it.
-    executed = trunk_flops(batch) * 16.0 / 15.0 if tk == "ring" else batch * 9216 * 2048.0
+    executed = batch * 9216 * 2048.0
     executed_tf = executed / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
     direct_tf = trunk_flops(batch) / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
     arena_gb = eng.pool.arena_bytes() / 1e9 if hasattr(eng.pool, "arena_bytes") else None

@@ -127,7 +127,10 @@ int apz_sample_moves_keyed_host(apz_engine *e, const int32_t *visits_host, int g
  * weight-gradient of the 3x3 convolutions, callable on caller-owned dense NCHW float32 device
  * tensors, e.g. from a torch.autograd.Function).  `stream` = the hipStream_t to launch on (NULL is
  * the null stream, which is what torch.cuda.current_stream().cuda_stream reports by default);
- * APZ_ENGINE_STREAM selects the engine's own stream.  Supported: boards 15x15 and 8x8; packed C_out in {64, 128, 256}.
+ * APZ_ENGINE_STREAM selects the engine's own stream.  The training entry points share per-engine scratch buffers: calls on
+ * one stream are ordered by it, and a call on a DIFFERENT stream than the previous one is ordered (event + stream wait)
+ * behind everything that was queued on the previous stream -- one engine never works on two streams at once.
+ * Supported: boards 15x15 and 8x8; packed C_out in {64, 128, 256}.
  *   apz_conv3x3_pack   w_dev [cout][cin][3][3] -> wpk_dev (apz_conv3x3_packed_size floats);
  *                      transpose_flip=1 packs the weights of the data-gradient convolution
  *                      dX = conv(dY, W'), W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
@@ -247,6 +250,12 @@ int apz_layer_io(apz_engine *e, int layer, float *host_out, int64_t count);
  * keeps the measured run undisturbed); then read out[0] = total ms, out[1] = timed launches
  * (resolved at apz_sync). */
 int apz_set_profiling(apz_engine *e, int on);
+/* TEST HOOK.  The 15x15 / 128-filter residual net has two trunk convolution kernels: the fused F(4x4,3x3) Winograd kernel
+ * (default, csrc/trunk15_wino3.h) and the direct convolution (csrc/trunk15_ring.h) that the tests use as the in-tree
+ * cross-check of the former (exact fp32 FMA chains, no transform).  Takes effect from the next forward. */
+#define APZ_TRUNK_DIRECT 0
+#define APZ_TRUNK_WINOGRAD 3
+int apz_test_select_trunk(apz_engine *e, int kind);
 int apz_kernel_time_ms(apz_engine *e, int kernel_class, float *out2);
 /* Enqueue `iters` forwards of n empty boards on the engine's stream and return without waiting (apz_sync waits).
  * GPU-only warm-up for measurements: clocks, the runtime's event / signal pools, instruction caches.  The results go

@@ -24,7 +24,7 @@ def pack_params(prm, n_blocks):
 
 
 class CNet(object):
-    def __init__(self, prm, height, width, c_in=9, n_filter=128, n_blocks=10, fast=True):
+    def __init__(self, prm, height, width, c_in=9, n_filter=128, n_blocks=10, fast=False):
         if not os.path.exists(LIB):
             raise RuntimeError("%s missing: run `python -m alphapig_amd.build oracle`" % LIB)
         self.L = C.CDLL(LIB)

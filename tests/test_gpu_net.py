@@ -300,29 +300,22 @@ def test_empty_and_ragged_batches(resnet3):
 
 
 def _net_with_trunk_kernel(kind, prm, n_blocks, batch):
-    """APZ_TRUNK_KERNEL is read by apz_create: ring = direct convolution, wino / wino2 / wino3 = the fused
-    F(4x4,3x3) Winograd kernels (one board / a pair of boards in two position passes / a pair of boards x
-    64 output channels in one pass, the default)."""
+    """kind "ring" = the direct convolution (trunk15_ring_kernel: exact fp32 FMA chains, the in-tree cross-check), "wino3" = the
+    fused F(4x4,3x3) Winograd kernel (default); selected through the C ABI's test hook apz_test_select_trunk."""
     from alphapig_amd.policy_value_net import PolicyValueNet
-    old = os.environ.get("APZ_TRUNK_KERNEL")
-    os.environ["APZ_TRUNK_KERNEL"] = kind
-    try:
-        return PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm)
-    finally:
-        if old is None:
-            del os.environ["APZ_TRUNK_KERNEL"]
-        else:
-            os.environ["APZ_TRUNK_KERNEL"] = old
+    net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm)
+    net._ck(net.L.apz_test_select_trunk(net._h, {"ring": 0, "wino3": 3}[kind]))
+    return net
 
 
 @pytest.mark.parametrize("n", [1, 2, 7, 33])
 def test_trunk_kernels_against_oracle(n):
-    """Every trunk kernel variant (direct, Winograd, Winograd pair, single-pass pair) against the float64 oracle: layer
+    """Both trunk kernels (direct, single-pass Winograd pair) against the float64 oracle: layer
     outputs of a plain and of a residual trunk convolution, logits within the path's 1e-4."""
     prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=11, style="bench")
     _, planes = random_positions(n, 15, seed=300 + n)
     o_logits, _, o_vlog, _, (o_stem, o_trunk) = net_ref.forward(prm, planes, "resnet", 2, np.float64, True)
-    for kind in ("ring", "wino", "wino2", "wino3"):
+    for kind in ("ring", "wino3"):
         net = _net_with_trunk_kernel(kind, prm, 2, 64)
         try:
             logits, _, vlog, _ = net.forward_with_logits(planes)
@@ -342,18 +335,18 @@ def test_trunk_kernels_agree_on_a_large_ragged_batch():
     prm = weights.init_params("resnet", 15, 15, 9, 1, 128, seed=12, style="bench")
     _, planes = random_positions(n, 15, seed=77)
     outs = {}
-    for kind in ("ring", "wino", "wino2", "wino3"):
+    for kind in ("ring", "wino3"):
         net = _net_with_trunk_kernel(kind, prm, 1, n)
         try:
             p, v = net.forward_planes(planes)
             outs[kind] = (p, v, net.layer_output(1, n), net.layer_output(2, n))
         finally:
             net.close()
-    for kind in ("wino", "wino2", "wino3"):
+    for kind in ("wino3",):
         for a, b in zip(outs[kind], outs["ring"]):
             np.testing.assert_allclose(a, b, rtol=0, atol=5e-5, err_msg=kind)
     # the same board gives the same bits wherever it sits in the batch (position-independent kernels)
-    for kind in ("wino2", "wino3"):
+    for kind in ("wino3",):
         net = _net_with_trunk_kernel(kind, prm, 1, n)
         try:
             perm = np.random.RandomState(0).permutation(n)

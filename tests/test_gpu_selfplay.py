@@ -184,6 +184,23 @@ def test_rccl_collectives_world_size_1():
     assert r.returncode == 0 and "rccl world_size=1 ok" in r.stdout, r.stdout[-2000:]
 
 
+def test_rccl_training_pipeline_world_size_1():
+    """configs[4]'s loop with the real HIP trainer and evaluator, collectives on RCCL (one rank): self-play ->
+    all_gather_tuples -> policy_update (train_mxnet.py:194-240) -> flat weight broadcast -> load_device_params
+    (policy_value_net_mxnet.py:295-297 across ranks).  The 2-rank plumbing runs on gloo in tests/test_pipeline_dist.py."""
+    pytest.importorskip("torch")
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_PORT"] = "29613"
+    r = subprocess.run([sys.executable, os.path.join(here, "_rccl_worker.py"), "pipeline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "rccl pipeline ok" in r.stdout, r.stdout[-3000:]
+
+
 def test_arena_on_gpu_equals_sequential_oracle_on_recorded_outputs():
     """SURVEY 8f rank 3 on the GPU: `policy_evaluate` (train_mxnet.py:242-263 -> Game.start_play, game.py:204-230)
     as M concurrent matches through the HIP evaluator.  The evaluator outputs the GPU produced are recorded and

@@ -1,5 +1,6 @@
-// Timing + cross-check harness for trunk15_wino3_kernel: random data, HIP events, outputs compared with
-// trunk15_wino2_kernel (which tests/test_gpu_net.py holds to the float64 oracle).
+// Timing + cross-check harness for trunk15_wino3_kernel: random data, HIP events, outputs compared with a naive
+// double-precision kernel of the same Winograd-domain definition (wino_ref_kernel below: one thread per (board, output
+// channel, tile)) and, for board 0, with a CPU loop.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Ialphapig_amd/csrc [-DAPZ_WINO3_STAMPS] tools/wino3_bench.hip -o tools/_build/wino3_bench
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -7,17 +8,67 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "trunk15_wino2.h"
 #include "trunk15_wino3.h"
+
+// Y = A^T [sum_ci U (.) B^T d B] A + bias (+ resid), ReLU -- the definition, in double, no tiling tricks.
+// in / res / out: rows16 [n][128][15][16]; upk: wino_common.h's packed layout.
+__global__ void wino_ref_kernel(const float* __restrict__ in, const float* __restrict__ upk, const float* __restrict__ bias,
+                                const float* __restrict__ res, float* __restrict__ out, int n, int resid) {
+    const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (gid >= (long)n * 128 * 16) return;
+    const int tile = (int)(gid & 15), co = (int)((gid >> 4) & 127), bd = (int)(gid >> 11);
+    const int ty = tile >> 2, tx = tile & 3;
+    const double Bt[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                             {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    const double At[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    double M[6][6];
+    for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 6; k++) M[i][k] = 0.0;
+    const int cot = co >> 4, j = co & 15;
+    for (int ci = 0; ci < 128; ci++) {
+        double d[6][6], t[6][6];
+        const float* pl = in + ((size_t)bd * 128 + ci) * 240;
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) {
+                const int r = 4 * ty - 1 + i, c = 4 * tx - 1 + k;
+                d[i][k] = (r >= 0 && r < 15 && c >= 0 && c < 15) ? (double)pl[r * 16 + c] : 0.0;
+            }
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) {
+                double a = 0;
+                for (int x = 0; x < 6; x++) a += Bt[i][x] * d[x][k];
+                t[i][k] = a;
+            }
+        const int c4 = ci >> 2, q = ci & 3;
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) {
+                double v = 0;
+                for (int x = 0; x < 6; x++) v += t[i][x] * Bt[k][x];
+                const int ph = i / 3, ii = i % 3;
+                M[i][k] += (double)upk[((((size_t)cot * 2 + ph) * 32 + c4) * 64 + q * 16 + j) * 20 + 6 * ii + k] * v;
+            }
+    }
+    float* op = out + ((size_t)bd * 128 + co) * 240;
+    const float* rp = res + ((size_t)bd * 128 + co) * 240;
+    for (int a = 0; a < 4; a++)
+        for (int e = 0; e < 4; e++) {
+            const int r = 4 * ty + a, c = 4 * tx + e;
+            if (r >= 15) continue;
+            double acc = 0;
+            for (int i = 0; i < 6; i++)
+                for (int k = 0; k < 6; k++) acc += At[a][i] * M[i][k] * At[e][k];
+            acc += (double)bias[co];
+            if (resid && c < 15) acc += (double)rp[r * 16 + c];
+            op[r * 16 + c] = c < 15 ? (float)(acc > 0 ? acc : 0.0) : 0.f;
+        }
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    using T2 = apz::Wino2;
+    using T2 = apz::WinoPack;
     using T3 = apz::Wino3;
     const char* tag = argc > 1 ? argv[1] : "wino3";
-    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2::LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2::LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
     const int nmax = 4096;
@@ -89,23 +140,20 @@ int main(int argc, char** argv) {
                     }
             }
     };
-    // ---- cross-check against wino2 at ragged sizes (odd batch, fewer pairs than CUs, several pairs per workgroup)
+    // ---- cross-check against the naive kernel at ragged sizes (odd batch, fewer pairs than CUs, several pairs per workgroup)
     int bad = 0;
     const int check_sizes[7] = {1, 7, 64, 96, 512, 515, 1030};
     for (int ci = 0; ci < (getenv("APZ_NO_TIMING") ? 2 : 7); ci++) {
         const int n = check_sizes[ci];
-        const int grid = (n + 1) / 2 < 256 ? (n + 1) / 2 : 256;   // wino2: one workgroup per pair
         const int grid3 = apz::wino3_grid(n, 256);
         for (int resid = 0; resid < 2; resid++) {
             CK(hipMemset(out, 0xff, (size_t)n * 128 * 240 * 4));
-            CK(hipMemset(out2, 0xff, (size_t)n * 128 * 240 * 4));
-            if (resid) {
-                hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+            CK(hipMemset(out2, 0, (size_t)n * 128 * 240 * 4));
+            hipLaunchKernelGGL(wino_ref_kernel, dim3((n * 128 * 16 + 255) / 256), dim3(256), 0, 0, in, upk, bias, res, out2, n, resid);
+            if (resid)
                 hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
-            } else {
-                hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+            else
                 hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
-            }
             CK(hipDeviceSynchronize());
 #ifdef APZ3_DEBUG_X
             if (n == 1 && !resid) {
@@ -147,7 +195,7 @@ int main(int argc, char** argv) {
                         e3 = std::max(e3, std::fabs(yr[i] - a[(size_t)chans[cc] * 240 + i]));
                         e2 = std::max(e2, std::fabs(yr[i] - b[(size_t)chans[cc] * 240 + i]));
                     }
-                    printf("   cpu ref co %3d resid %d: max|wino3-ref| %.3e  max|wino2-ref| %.3e\n", chans[cc], resid, e3, e2);
+                    printf("   cpu ref co %3d resid %d: max|wino3-cpu| %.3e  max|naive-cpu| %.3e\n", chans[cc], resid, e3, e2);
                 }
             }
             const bool ok = nan == 0 && pad_bad == 0 && maxd < 2e-5 * (1.0 + maxv);
@@ -158,12 +206,12 @@ int main(int argc, char** argv) {
                     if (!(d < 2e-5 * (1.0 + maxv))) {
                         const int col = i & 15, row = (i / 16) % 15, co = (i / 240) % 128, bd = (int)(i / (240 * 128));
                         by_ct[co / 16]++; by_par[bd & 1]++; by_row[row]++; by_col[col]++;
-                        if (shown++ < 6) printf("   bd %d co %d row %d col %d: wino3 %g wino2 %g\n", bd, co, row, col, a[i], b[i]);
+                        if (shown++ < 6) printf("   bd %d co %d row %d col %d: wino3 %g naive %g\n", bd, co, row, col, a[i], b[i]);
                     }
                 }
                 if (n == 1 && getenv("APZ_DUMP")) {
                     for (int co = 8; co < 11; co++) {
-                        printf("   plane co %d (wino3 | wino2)\n", co);
+                        printf("   plane co %d (wino3 | naive)\n", co);
                         for (int row = 0; row < 15; row++) {
                             printf("    ");
                             for (int col = 0; col < 16; col++) printf("%7.2f", a[(size_t)co * 240 + row * 16 + col]);
@@ -179,7 +227,7 @@ int main(int argc, char** argv) {
                 printf("\n   by col:"); for (int k = 0; k < 16; k++) printf(" %d", by_col[k]);
                 printf("\n");
             }
-            printf("check n=%5d resid=%d: max|wino3-wino2| %.3e (max|ref| %.3f) nan %zu pad %zu  %s\n", n, resid, maxd, maxv, nan, pad_bad,
+            printf("check n=%5d resid=%d: max|wino3-naive| %.3e (max|ref| %.3f) nan %zu pad %zu  %s\n", n, resid, maxd, maxv, nan, pad_bad,
                    ok ? "ok" : "MISMATCH");
             if (!ok) bad++;
         }
@@ -191,18 +239,12 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < (getenv("APZ_NO_TIMING") ? 0 : 2); rep++)
     for (int si = 0; si < 4; si++) {
         const int n = sizes[si];
-        const int grid = (n + 1) / 2 < 256 ? (n + 1) / 2 : 256;   // wino2: one workgroup per pair
         const int grid3 = apz::wino3_grid(n, 256);
-        for (int kern = 0; kern < 2; kern++)
+        for (int kern = 1; kern < 2; kern++)
         for (int resid = 0; resid < 2; resid++) {
             auto launch = [&]() {
-                if (kern == 0) {
-                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino2_kernel<true>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out, n);
-                    else hipLaunchKernelGGL((apz::trunk15_wino2_kernel<false>), dim3(grid), dim3(512), T2::LDS_BYTES, 0, in, upk, bias, res, out, n);
-                } else {
-                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
-                    else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
-                }
+                if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
             };
             for (int i = 0; i < 5; i++) launch();
             CK(hipEventRecord(a, 0));
@@ -213,7 +255,7 @@ int main(int argc, char** argv) {
             float ms;
             CK(hipEventElapsedTime(&ms, a, b));
             const double us = ms * 1e3 / iters;
-            printf("%-8s %s n=%5d resid=%d: %8.1f us  executed-MFMA %.1f TF (%.3f of 157.3)  alg %.0f TF\n", tag, kern ? "wino3" : "wino2", n, resid, us,
+            printf("%-8s %s n=%5d resid=%d: %8.1f us  executed-MFMA %.1f TF (%.3f of 157.3)  alg %.0f TF\n", tag, "wino3", n, resid, us,
                    (double)n * 9216 * 2048 / us / 1e6, (double)n * 9216 * 2048 / us / 1e6 / 157.3, 2.0 * n * 128 * 128 * 9 * 225 / us / 1e6);
         }
     }
