@@ -18,6 +18,7 @@
 #include "heads.h"
 #include "trunk15_ring.h"
 #include "trunk15_wino3.h"
+#include "conv8_small.h"
 #include "wgrad_wino2.h"
 #include "sampler.h"
 #include "conv_train.h"
@@ -57,6 +58,7 @@ struct ConvLayer {
     int cin, cin_pad, cout;
     bool residual;          // add the block input before ReLU
     float* wpk = nullptr;
+    float* wpk12 = nullptr; // 8x8 boards (conv8_kernel): [cot][c4][lane][12]
     float* upk2 = nullptr;  // trunk15_wino3_kernel: transformed weights G g G^T, [cot][row half][c4][lane][20] (wino_common.h)
     float* bias = nullptr;
 };
@@ -103,6 +105,8 @@ struct apz_engine {
     // set_params or the arena -- every such call now queues behind the submissions instead of racing them.
     std::recursive_mutex submit_lock;
     bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
+    bool small8 = false;    // 8x8 boards: conv8_kernel / head8_kernel (conv8_small.h)
+    float* wfc_raw = nullptr;   // head8_kernel: the policy FullyConnected weight as stored, [hw][4 hw]
     int act_ps = 0, act_rs = 0;
     bool lds_attr_set[32] = {false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done, per kernel variant
     int conv_lds_set[16] = {0};
@@ -412,8 +416,35 @@ int launch_stem15(apz_engine* e, const ConvLayer& L, const float* in, float* out
     return fail(APZ_E_UNSUPPORTED, "stem15: C_in must be 4 or 9");
 }
 
+// 8x8 boards: work item = (board, 16 output channels), the contraction split over the four waves (conv8_small.h)
+template <bool RESID, bool CODES>
+int launch_conv8_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Conv8;
+    bool& configured = e->lds_attr_set[28 + (RESID ? 1 : 0) + (CODES ? 2 : 0)];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::conv8_kernel<RESID, CODES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T::LDS_BYTES));
+        configured = true;
+    }
+    const long items = (long)n * (L.cout / 16);
+    const int grid = (int)std::min<long>(items, 2L * e->num_cu);       // two workgroups per CU (LDS), persistent over items
+    hipLaunchKernelGGL((apz::conv8_kernel<RESID, CODES>), dim3(grid), dim3(256), T::LDS_BYTES, e->stream, in, L.wpk12, L.bias,
+                       resid, out, n, L.cin, L.cin_pad / 4, L.cout, 1, (int)e->code_stride);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int launch_conv8(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n,
+                 const unsigned char* codes = nullptr) {
+    if (L.cout % 16 || !L.wpk12) return fail(APZ_E_UNSUPPORTED, "conv8: C_out must be a multiple of 16");
+    if (codes) return launch_conv8_t<false, true>(e, L, (const float*)codes, nullptr, out, n);
+    if (resid) return launch_conv8_t<true, false>(e, L, in, resid, out, n);
+    return launch_conv8_t<false, false>(e, L, in, nullptr, out, n);
+}
+
 int launch_conv(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
     const int H = e->cfg.height, W = e->cfg.width, ct = L.cout / 64;
+    if (e->small8) return launch_conv8(e, L, in, resid, out, n);
     if (e->ring && &L != &e->convs[0]) return launch_trunk_ring(e, L, in, resid, out, n);
     if (e->ring) return launch_stem15(e, L, in, out, n);
     if (H == 15 && W == 15) {
@@ -436,16 +467,15 @@ int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** resul
     const int last = std::min(upto, nl - 1);
     {
         Timed tm(e, APZ_K_STEM);
-        if (e->cfg.net_kind == APZ_NET_RESNET) {
-            int rc = (codes && e->ring) ? launch_stem15(e, e->convs[0], nullptr, x, n, codes)
-                                        : launch_conv(e, e->convs[0], cur, nullptr, x, n);
-            if (rc) return rc;
-            cur = x;
-        } else {
-            int rc = launch_conv(e, e->convs[0], cur, nullptr, x, n);
-            if (rc) return rc;
-            cur = x;
-        }
+        int rc;
+        if (codes && e->small8)
+            rc = launch_conv8(e, e->convs[0], nullptr, nullptr, x, n, codes);       // the first layer decodes the codes itself
+        else if (codes && e->ring && e->cfg.net_kind == APZ_NET_RESNET)
+            rc = launch_stem15(e, e->convs[0], nullptr, x, n, codes);
+        else
+            rc = launch_conv(e, e->convs[0], cur, nullptr, x, n);
+        if (rc) return rc;
+        cur = x;
     }
     if (last >= 1) {
         Timed tm(e, APZ_K_TRUNK);       // all trunk launches of this forward under one event pair
@@ -476,7 +506,7 @@ int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** resul
 }
 
 // codes_dev != nullptr (stem_takes_codes(e) only): the position codes instead of `planes`
-bool stem_takes_codes(const apz_engine* e) { return e->ring && e->cfg.net_kind == APZ_NET_RESNET; }
+bool stem_takes_codes(const apz_engine* e) { return (e->ring && e->cfg.net_kind == APZ_NET_RESNET) || e->small8; }
 
 int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* values, float* logits,
                 float* vlogits, const unsigned char* codes_dev = nullptr) {
@@ -492,6 +522,14 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
     int rc = run_trunk(e, planes, n, (int)e->convs.size() - 1, &trunk, codes_dev);
     if (rc) return rc;
     const int hw = e->hw;
+    if (e->small8) {                    // both 1x1 convolutions, both FullyConnected layers, softmax and tanh in one launch
+        Timed tm(e, APZ_K_HEAD_FC);
+        hipLaunchKernelGGL(apz::head8_kernel, dim3(std::min(n, e->num_cu * 8)), dim3(256), 0, e->stream, trunk, e->w6, e->b6,
+                           e->wfc_raw, e->bfc, e->wv, e->bv, probs, values, logits, vlogits, n, e->clast);
+        HIP_TRY(hipGetLastError());
+        e->last_n = n;
+        return APZ_OK;
+    }
     {
         Timed tm(e, APZ_K_HEAD_CONV);
         if (e->ring && e->clast % 32 == 0)
@@ -573,11 +611,13 @@ void apz_destroy(apz_engine* e) {
     for (auto& l : e->convs) {
         if (l.wpk) hipFree(l.wpk);
         if (l.upk2) hipFree(l.upk2);
+        if (l.wpk12) hipFree(l.wpk12);
         if (l.bias) hipFree(l.bias);
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws};
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws,
+                   e->wfc_raw};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -638,6 +678,7 @@ apz_engine* apz_create(const apz_config* cfg) {
     if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", err);
     e->ring = cfg->net_kind == APZ_NET_RESNET && cfg->height == 15 && cfg->width == 15 && cfg->n_filter == 128;
+    e->small8 = cfg->height == 8 && cfg->width == 8;
     e->act_ps = e->ring ? apz::Trunk15::GPLANE : e->hw;
     e->act_rs = e->ring ? apz::Trunk15::GROW : cfg->width;
     const size_t B = cfg->max_batch, hw = e->hw;
@@ -727,6 +768,20 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
         if (rc) return rc;
         rc = upload(&L.bias, bias);
         if (rc) return rc;
+        if (e->small8) {                // conv8_kernel: the nine taps of a lane side by side, [cot][c4][lane][12]
+            std::vector<float> pk12((size_t)ncot * n4 * 64 * 12, 0.f);
+            for (int cot = 0; cot < ncot; cot++)
+                for (int c4 = 0; c4 < n4; c4++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int co = cot * 16 + (lane & 15), ci = c4 * 4 + (lane >> 4);
+                        if (ci >= L.cin) continue;
+                        for (int tap = 0; tap < 9; tap++)
+                            pk12[(((size_t)cot * n4 + c4) * 64 + lane) * 12 + tap] =
+                                (float)((double)w[((size_t)co * L.cin + ci) * 9 + tap] * scale[co]);
+                    }
+            rc = upload(&L.wpk12, pk12);
+            if (rc) return rc;
+        }
         if (x4) {
             // F(4x4,3x3) Winograd weights U[pos = 6i+k][co][ci] = (G g G^T)[i][k] of the BN-folded kernel g, in double,
             // rounded once; packed [cot 8][row half 2][c4 32][lane 64][20] (wino_common.h)
@@ -784,6 +839,10 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
         std::vector<float> wv(P.at("fc_3_2_1_weight"), P.at("fc_3_2_1_weight") + 2 * hw);
         std::vector<float> bv(P.at("fc_3_2_1_bias"), P.at("fc_3_2_1_bias") + 1);
         int rc;
+        if (e->small8) {
+            std::vector<float> raw(wfc, wfc + (size_t)hw * K);
+            if ((rc = upload(&e->wfc_raw, raw))) return rc;
+        }
         if ((rc = upload(&e->w6, w6)) || (rc = upload(&e->b6, b6)) || (rc = upload(&e->wfc_pk, pk)) ||
             (rc = upload(&e->bfc, bfc)) || (rc = upload(&e->wv, wv)) || (rc = upload(&e->bv, bv)))
             return rc;
@@ -1086,6 +1145,9 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
                                L.cin, n4, ncot, (int)x4);
             if (x4)
                 hipLaunchKernelGGL(apz::pack_wino_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale, L.upk2);
+            if (e->small8 && L.wpk12)
+                hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale,
+                                   L.wpk12, L.cin, n4, ncot, 1);
             HIP_TRY(hipGetLastError());
         }
         const int C = e->clast, hw = e->hw;
@@ -1099,6 +1161,8 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
         hipLaunchKernelGGL(apz::pack_fc_kernel, dim3(std::min((ntile * KG * 512 + 255) / 256, 2048)), dim3(256), 0, st,
                            P.at("fc_3_1_1_weight"), e->wfc_pk, hw, ntile, KG);
         HIP_TRY(hipGetLastError());
+        if (e->small8 && e->wfc_raw)
+            HIP_TRY(hipMemcpyAsync(e->wfc_raw, P.at("fc_3_1_1_weight"), (size_t)hw * 4 * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(e->bfc, P.at("fc_3_1_1_bias"), hw * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(e->wv, P.at("fc_3_2_1_weight"), 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(e->bv, P.at("fc_3_2_1_bias"), sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -219,6 +219,23 @@ class PolicyValueNet(object):
         self._ck(self.L.apz_wait(self._h, int(slot), as_ptr(probs, C.c_float), as_ptr(vals, C.c_float)))
         return probs, vals
 
+    def submit_codes_slot(self, slot, codes):
+        """Enqueue one batch on `slot` (apz_submit_codes: copies the codes into the slot's pinned buffer, queues the forward
+        and an event on the engine's one stream) and return at once -> n.  Pair with wait_slot."""
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.code_stride)
+        n = c.shape[0]
+        if n > self.batchsize or n == 0:
+            raise EvaluatorError("submit_codes_slot: batch of %d outside [1, %d]" % (n, self.batchsize))
+        self._ck(self.L.apz_submit_codes(self._h, int(slot), as_ptr(c, C.c_uint8), n))
+        return n
+
+    def wait_slot(self, slot, n):
+        """Block until the batch submitted on `slot` is done -> (probs [n, HW], values [n])."""
+        probs = np.empty((n, self.hw), dtype=np.float32)
+        vals = np.empty(n, dtype=np.float32)
+        self._ck(self.L.apz_wait(self._h, int(slot), as_ptr(probs, C.c_float), as_ptr(vals, C.c_float)))
+        return probs, vals
+
     def sample_moves(self, visits, temp=1.0, alpha=0.3, eps=0.25, seed=0, step=0, keys=None):
         """GPU root sampling (opt-in perf mode): visits int32 [g, HW] with -1 for non-children ->
         (pi float32 [g, HW], moves int32 [g]).  keys: optional uint64 [g]; row i's draw then depends on

@@ -60,6 +60,10 @@ class SelfPlayEngine(object):
         # pipeline group keep one batch queued on the SAME HIP stream: group B's kernels start the
         # moment group A's last kernel ends, while kernels never run concurrently (clean timings).
         self._slotted = hasattr(self.evaluator, "evaluate_codes_slot")
+        # ... and one whose submit returns at once (submit_codes_slot / wait_slot) needs no worker threads at all: the
+        # scheduler thread queues group A's batch, advances group B while the GPU works, and only then waits for A --
+        # no GIL hand-offs between threads inside a step (they cost more than the whole host side of a 32-leaf step)
+        self._async = self._slotted and hasattr(self.evaluator, "submit_codes_slot") and hasattr(self.evaluator, "wait_slot")
         self.G, self.hw = int(n_games), board_width * board_height
         self.n_playout, self.temp = int(n_playout), temp
         # The reference plays every ply at one constant `temp`.  Optional extension
@@ -91,7 +95,11 @@ class SelfPlayEngine(object):
         self._limit = None
         n_workers = min(self.pipeline, getattr(self.evaluator, "n_slots", 1)) if self._slotted else 1
         # one worker thread per slot; a worker serves its own groups in order
-        self._exec = ([ThreadPoolExecutor(max_workers=1) for _ in range(n_workers)] if self.pipeline > 1 else None)
+        self._n_slots = max(1, n_workers)
+        if self.pipeline > self._n_slots:           # two groups would share a slot: keep the one-worker-per-slot queues
+            self._async = False
+        self._exec = ([ThreadPoolExecutor(max_workers=1) for _ in range(n_workers)]
+                      if self.pipeline > 1 and not self._async else None)
 
     # ---- slot life cycle -------------------------------------------------------------------
     def _start_game(self, s):
@@ -224,6 +232,31 @@ class SelfPlayEngine(object):
         self.timers["eval_s"] += time.perf_counter() - t0
         return out
 
+    def _dispatch(self, gi, ids, codes):
+        """Start the evaluation of one group's leaves -> a ticket for _collect."""
+        if self._async and len(ids) <= getattr(self.evaluator, "batchsize", len(ids)):
+            slot = gi % self._n_slots
+            t0 = time.perf_counter()
+            n = self.evaluator.submit_codes_slot(slot, codes)
+            self.timers["eval_s"] += time.perf_counter() - t0
+            return ("slot", slot, n, ids)
+        if self._exec is not None:
+            w = gi % len(self._exec)
+            return ("future", self._exec[w].submit(self._evaluate, codes, w), ids)
+        return ("done", self._evaluate(codes), ids)
+
+    def _collect(self, ticket):
+        """-> (probs, values, ids) of a dispatched group (blocks until the GPU is done with it)."""
+        if ticket[0] == "slot":
+            t0 = time.perf_counter()
+            p, v = self.evaluator.wait_slot(ticket[1], ticket[2])
+            self.timers["eval_s"] += time.perf_counter() - t0
+            return p, v, ticket[3]
+        if ticket[0] == "future":
+            p, v = ticket[1].result()
+            return p, v, ticket[2]
+        return ticket[1][0], ticket[1][1], ticket[2]
+
     def _groups(self):
         return [list(range(g, self.G, self.pipeline)) for g in range(self.pipeline)]
 
@@ -245,8 +278,7 @@ class SelfPlayEngine(object):
             t_step = time.perf_counter()
             for gi, grp in enumerate(groups):
                 if gi in inflight:                       # finish this group's previous evaluation
-                    ids, fut = inflight.pop(gi)
-                    p, v = fut.result() if self._exec is not None else fut
+                    p, v, ids = self._collect(inflight.pop(gi))
                     t0 = time.perf_counter()
                     self.pool.feed(ids, p, v)
                     self.timers["host_s"] += time.perf_counter() - t0
@@ -254,18 +286,13 @@ class SelfPlayEngine(object):
                 ids, codes = self._advance_group(grp)    # overlaps the other groups' evaluations
                 if len(ids):
                     busy = True
-                    if self._exec is not None:
-                        w = gi % len(self._exec)
-                        inflight[gi] = (ids, self._exec[w].submit(self._evaluate, codes, w))
-                    else:
-                        inflight[gi] = (ids, self._evaluate(codes))
+                    inflight[gi] = self._dispatch(gi, ids, codes)
             if step_times is not None:
                 step_times.append(time.perf_counter() - t_step)
             if not busy:
                 break
         for gi in sorted(inflight):
-            ids, fut = inflight[gi]
-            p, v = fut.result() if self._exec is not None else fut
+            p, v, ids = self._collect(inflight[gi])
             self.pool.feed(ids, p, v)
             leafs += len(ids)
         self.stats["leaf_evals"] += leafs

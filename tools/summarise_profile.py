@@ -52,6 +52,22 @@ def main():
             avg = sum(v) / len(v)
             print("| `%s` | %d | %.1f | %.0f | %s |" % (short(k), len(v), avg, avg * 1024,
                                                      ("%.0f" % (avg * 2048)) if ctr == "FETCH_SIZE" else "-"))
+    # ---- SQ / GRBM passes (tools/profile_gpu.sh: pmc_sq_a, pmc_sq_b, pmc_grbm): per-dispatch averages of every counter
+    for sub in ("pmc_sq_a", "pmc_sq_b", "pmc_grbm"):
+        acc = defaultdict(lambda: defaultdict(list))
+        for f in find(os.path.join(root, sub), "*counter_collection.csv"):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if not acc:
+            continue
+        names = sorted({c for k in acc for c in acc[k]})
+        print("\n## PMC %s (own pass; average per dispatch, summed over the chip)\n" % sub)
+        print("| kernel | dispatches | " + " | ".join(names) + " |")
+        print("|---|---:|" + "---:|" * len(names))
+        for k, cs in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
+            n = max(len(v) for v in cs.values())
+            print("| `%s` | %d | " % (short(k), n) + " | ".join(("%.4g" % (sum(cs[c]) / len(cs[c]))) if c in cs else "-" for c in names) + " |")
 
 
 if __name__ == "__main__":
