@@ -18,6 +18,7 @@
 #include "heads.h"
 #include "trunk15_ring.h"
 #include "trunk15_wino3.h"
+#include "trunk15_wino3s.h"
 #include "conv8_small.h"
 #include "wgrad_wino2.h"
 #include "sampler.h"
@@ -60,6 +61,7 @@ struct ConvLayer {
     float* wpk = nullptr;
     float* wpk12 = nullptr; // 8x8 boards (conv8_kernel): [cot][c4][lane][12]
     float* upk2 = nullptr;  // trunk15_wino3_kernel: transformed weights G g G^T, [cot][row half][c4][lane][20] (wino_common.h)
+    float* upk3s = nullptr; // trunk15_wino3s_kernel: the same values, [cot][wave][c4][piece][lane][4] (WinoPackSmall)
     float* bias = nullptr;
 };
 
@@ -130,6 +132,9 @@ struct apz_engine {
     bool wgrad_attr_set[2] = {false, false};
     hipStream_t scratch_stream = nullptr;          // the stream of the last entry point that may have used the scratch buffers
     bool scratch_stream_valid = false;
+    float* w3s_slabs = nullptr;              // trunk15_wino3s_kernel: row partials of the position halves
+    unsigned* w3s_tickets = nullptr;         // ... and the pairs' ticket counters (zeroed once; every launch adds two to each it uses)
+    bool no_small_trunk = false;             // apz_test_select_trunk(APZ_TRUNK_WINOGRAD_BATCHED): tests compare the two forms
     int trunk_kernel = APZ_TRUNK_WINOGRAD;   // or APZ_TRUNK_DIRECT (trunk15_ring_kernel): apz_test_select_trunk, tests only
     // profiling
     bool profiling = false;
@@ -358,13 +363,28 @@ static_assert((long long)WINO3_MAX_BOARDS * 128 * 960 < (1ll << 31), "wino3 buff
 
 template <bool RESID, bool RELU>
 int launch_wino3_t(apz_engine* e, int attr_slot, const float* in, const float* upk, const float* bias, const float* resid,
-                   float* out, int n) {
+                   float* out, int n, const float* upk_small = nullptr) {
     using T = apz::Wino3;
     bool& configured = e->lds_attr_set[attr_slot];
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<RESID, RELU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3s_kernel<RESID, RELU>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, apz::Wino3S::LDS_BYTES));
         configured = true;
+    }
+    if (upk_small && n <= apz::Wino3S::MAX_BOARDS && !e->no_small_trunk) {
+        // the latency path: sixteen workgroups per board (16 output channels x half the positions), the same bits
+        // (csrc/trunk15_wino3s.h); the halves meet through global slabs + ticket counters that are never reset
+        if (!e->w3s_slabs) {
+            HIP_TRY(hipMalloc((void**)&e->w3s_slabs, apz::Wino3S::slab_floats() * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&e->w3s_tickets, apz::Wino3S::counters() * sizeof(unsigned)));
+            HIP_TRY(hipMemset(e->w3s_tickets, 0, apz::Wino3S::counters() * sizeof(unsigned)));
+        }
+        hipLaunchKernelGGL((apz::trunk15_wino3s_kernel<RESID, RELU>), dim3(n * 16), dim3(256), apz::Wino3S::LDS_BYTES, e->stream, in,
+                           upk_small, bias, RESID ? resid : nullptr, out, n, e->w3s_slabs, e->w3s_tickets);
+        HIP_TRY(hipGetLastError());
+        return APZ_OK;
     }
     for (int b0 = 0; b0 < n; b0 += WINO3_MAX_BOARDS) {
         const int nb = std::min(n - b0, WINO3_MAX_BOARDS);
@@ -378,8 +398,8 @@ int launch_wino3_t(apz_engine* e, int attr_slot, const float* in, const float* u
 }
 
 int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
-    if (resid) return launch_wino3_t<true, true>(e, 6, in, L.upk2, L.bias, resid, out, n);
-    return launch_wino3_t<false, true>(e, 7, in, L.upk2, L.bias, nullptr, out, n);
+    if (resid) return launch_wino3_t<true, true>(e, 6, in, L.upk2, L.bias, resid, out, n, L.upk3s);
+    return launch_wino3_t<false, true>(e, 7, in, L.upk2, L.bias, nullptr, out, n, L.upk3s);
 }
 
 int launch_trunk_ring(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
@@ -611,13 +631,14 @@ void apz_destroy(apz_engine* e) {
     for (auto& l : e->convs) {
         if (l.wpk) hipFree(l.wpk);
         if (l.upk2) hipFree(l.upk2);
+        if (l.upk3s) hipFree(l.upk3s);
         if (l.wpk12) hipFree(l.wpk12);
         if (l.bias) hipFree(l.bias);
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
                    e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws,
-                   e->wfc_raw};
+                   e->wfc_raw, e->w3s_slabs, e->w3s_tickets};
     for (void* p : dev)
         if (p) hipFree(p);
     for (auto& sl : e->slots) {
@@ -788,7 +809,7 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
             static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6},
                                            {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
                                            {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-            std::vector<float> up2(apz::WinoPack::UPK_FLOATS, 0.f);
+            std::vector<float> up2(apz::WinoPack::UPK_FLOATS, 0.f), up3s(apz::WinoPackSmall::UPK_FLOATS, 0.f);
             for (int co = 0; co < 128; co++)
                 for (int ci = 0; ci < 128; ci++) {
                     double g[3][3], t[6][3];
@@ -802,9 +823,12 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
                             const double u = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
                             const int half = i / 3;
                             up2[((((size_t)cot * 2 + half) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * half) * 6 + k] = (float)u;
+                            up3s[apz::WinoPackSmall::index(co, ci, 6 * i + k)] = (float)u;
                         }
                 }
             rc = upload(&L.upk2, up2);
+            if (rc) return rc;
+            rc = upload(&L.upk3s, up3s);
             if (rc) return rc;
         }
     }
@@ -1144,7 +1168,7 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
             hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale, L.wpk,
                                L.cin, n4, ncot, (int)x4);
             if (x4)
-                hipLaunchKernelGGL(apz::pack_wino_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale, L.upk2);
+                hipLaunchKernelGGL(apz::pack_wino_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale, L.upk2, L.upk3s);
             if (e->small8 && L.wpk12)
                 hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale,
                                    L.wpk12, L.cin, n4, ncot, 1);
@@ -1797,10 +1821,12 @@ int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
 }
 
 int apz_test_select_trunk(apz_engine* e, int kind) {
-    if (!e || (kind != APZ_TRUNK_WINOGRAD && kind != APZ_TRUNK_DIRECT)) return fail(APZ_E_ARG, "bad trunk kernel kind");
+    if (!e || (kind != APZ_TRUNK_WINOGRAD && kind != APZ_TRUNK_DIRECT && kind != APZ_TRUNK_WINOGRAD_BATCHED))
+        return fail(APZ_E_ARG, "bad trunk kernel kind");
     EngineLock guard(e->submit_lock);
     if (!e->ring) return fail(APZ_E_UNSUPPORTED, "only the 15x15 / 128-filter residual net has two trunk kernels");
-    e->trunk_kernel = kind;
+    e->trunk_kernel = kind == APZ_TRUNK_DIRECT ? APZ_TRUNK_DIRECT : APZ_TRUNK_WINOGRAD;
+    e->no_small_trunk = kind == APZ_TRUNK_WINOGRAD_BATCHED;
     return APZ_OK;
 }
 

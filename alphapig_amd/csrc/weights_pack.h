@@ -4,6 +4,7 @@
 // modules after every step).  The host path costs a device -> host copy of every tensor, 16 ms of folding and
 // Winograd packing on one core and the upload; these kernels take a few tens of microseconds.  gfx950.
 #pragma once
+#include "wino_common.h"
 #include <hip/hip_runtime.h>
 
 namespace apz {
@@ -41,7 +42,8 @@ __global__ void pack_direct_kernel(const float* __restrict__ w, const double* __
 // F(4x4,3x3) Winograd weights of the 128 -> 128 trunk shape, U[6i+k][co][ci] = (G g G^T)[i][k] of the folded kernel, in
 // double, rounded once, in trunk15_wino3.h's layout (wino_common.h: [cot 8][row half 2][c4 32][lane 64][20]).  One thread
 // per (co, ci).
-__global__ void pack_wino_folded_kernel(const float* __restrict__ w, const double* __restrict__ scale, float* __restrict__ up2) {
+__global__ void pack_wino_folded_kernel(const float* __restrict__ w, const double* __restrict__ scale, float* __restrict__ up2,
+                                        float* __restrict__ up3s) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 128 * 128) return;
     const int co = idx >> 7, ci = idx & 127;
@@ -65,6 +67,7 @@ __global__ void pack_wino_folded_kernel(const float* __restrict__ w, const doubl
             const double u = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
             const int pass = i / 3;
             up2[((((size_t)cot * 2 + pass) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * pass) * 6 + k] = (float)u;
+            if (up3s) up3s[WinoPackSmall::index(co, ci, 6 * i + k)] = (float)u;
         }
 }
 

@@ -17,6 +17,18 @@ struct WinoPack {
     static constexpr size_t UPK_FLOATS = (size_t)8 * 2 * 32 * 64 * UROW;   // per layer (2.6 MB)
 };
 
+// The same values for the small-batch kernel (trunk15_wino3s.h), whose MFMA wave w owns positions 9 w .. 9 w + 8:
+// [cot 8][w 4][c4 32][piece 3][lane 64][4] -- value m = 4 piece + e of the wave's nine (pad: 0), so that one k-step of a
+// wave is three fully coalesced 1 KB loads (from the layout above it was nine loads touching forty 128-byte lines each).
+struct WinoPackSmall {
+    static constexpr int STEP = 3 * 64 * 4;            // floats per (cot, w, c4)
+    static constexpr size_t UPK_FLOATS = (size_t)8 * 4 * 32 * STEP;   // per layer (3.1 MB)
+    __host__ __device__ static size_t index(int co, int ci, int pos) {
+        const int cot = co >> 4, jj = co & 15, c4 = ci >> 2, qq = ci & 3, w = pos / 9, m = pos % 9;
+        return ((((size_t)(cot * 4 + w) * 32 + c4) * 3 + (m >> 2)) * 64 + (qq * 16 + jj)) * 4 + (m & 3);
+    }
+};
+
 __device__ __forceinline__ f32x2 fma2(const float a, const f32x2 b, const f32x2 c) {   // a*b + c (v_pk_fma_f32)
     return __builtin_elementwise_fma(f32x2{a, a}, b, c);
 }

@@ -267,10 +267,19 @@ class PolicyValueNet(object):
 
     def policy_value_fn(self, board):
         """(action, prob) pairs over the legal moves + value of the position for the player to
-        move (policy_value_net_mxnet.py:261-280): priors are NOT renormalised over legal moves."""
+        move (policy_value_net_mxnet.py:261-280): priors are NOT renormalised over legal moves.
+        A board that offers `position_codes()` (alphapig_amd.game.Board) is evaluated through the zero-copy slot: 240
+        bytes in, the first convolution builds the planes of `current_state()` itself (same bits as the planes entry
+        point, tests/test_gpu_net.py) -- no staging copies around a one-board forward.  Any other Board-like object
+        goes through `current_state()` exactly as in the reference."""
         legal = board.availables
-        state = np.ascontiguousarray(board.current_state(), dtype=np.float32)
-        probs, vals = self.forward_planes(state.reshape(1, self.channelnum, self.board_height, self.board_width))
+        codes = getattr(board, "position_codes", None)
+        if codes is not None and getattr(board, "width", None) == self.board_width and \
+                getattr(board, "height", None) == self.board_height:
+            probs, vals = self.evaluate_codes_slot(self.n_slots - 1, codes()[None])
+        else:
+            state = np.ascontiguousarray(board.current_state(), dtype=np.float32)
+            probs, vals = self.forward_planes(state.reshape(1, self.channelnum, self.board_height, self.board_width))
         return zip(legal, probs[0][legal]), vals[0:1]
 
     def train_step(self, state_batch, mcts_probs, winner_batch, learning_rate):

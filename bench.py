@@ -165,6 +165,34 @@ def _rank_log_dir():
         return tempfile.gettempdir()
 
 
+def latency_probe(device):
+    """The drop-in single-game API as the reference calls it (batch 1): one PolicyValueNet.policy_value_fn(board)
+    (policy_value_net_mxnet.py:261-280) and one MCTSPlayer.get_action at n_playout = 400 (mcts_alphaZero.py:187-218) on the
+    bench's 10-block net -- the small-batch kernels' line (csrc/trunk15_wino3s.h)."""
+    from alphapig_amd.game import Board
+    from alphapig_amd.mcts_alphaZero import MCTSPlayer
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
+    net = PolicyValueNet(W, H, batch_size=16, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, device=device)
+    b = Board(width=W, height=H, n_in_row=N_IN_ROW)
+    b.init_board(0)
+    for m in (112, 113, 97):
+        b.do_move(m)
+    for _ in range(50):
+        net.policy_value_fn(b)
+    t = time.perf_counter()
+    for _ in range(300):
+        net.policy_value_fn(b)
+    leaf_ms = (time.perf_counter() - t) / 300 * 1e3
+    p = MCTSPlayer(net.policy_value_fn, c_puct=5, n_playout=N_PLAYOUT, is_selfplay=0)
+    t = time.perf_counter()
+    p.get_action(b)
+    move_s = time.perf_counter() - t
+    net.close()
+    return {"policy_value_fn_ms": leaf_ms, "get_action_n_playout_400_s": move_s,
+            "what": "batch-1 calls of the reference API on the 10-block net, one board per forward (round 2: 1.0 ms / 0.43 s)"}
+
+
 def spawn_ranks(n, argv, deadline_s=1800.0, silence_s=420.0, early_exit_grace_s=60.0):
     """`--gpus N` outside a launcher: start N fresh rank processes (this process has not touched the GPU and never
     does), pass rank 0's JSON line through, fail -- non-zero exit, every rank killed -- if
@@ -632,6 +660,7 @@ def main():
         line["data"] = "plumbing-test (CPU stand-in evaluator, 8 games per rank): NOT a measurement"
     if not args.no_extras and world == 1 and not args.plumbing_test:
         line["roofline_stem"] = stem_roofline(local)
+        line["latency"] = latency_probe(local)
         line["cpu_baseline"] = cpu_baseline(mean_plies, cores=max(1, min(16, ncpu)))
     print(json.dumps(line))
 

@@ -254,7 +254,8 @@ int apz_set_profiling(apz_engine *e, int on);
  * (default, csrc/trunk15_wino3.h) and the direct convolution (csrc/trunk15_ring.h) that the tests use as the in-tree
  * cross-check of the former (exact fp32 FMA chains, no transform).  Takes effect from the next forward. */
 #define APZ_TRUNK_DIRECT 0
-#define APZ_TRUNK_WINOGRAD 3
+#define APZ_TRUNK_WINOGRAD 3            /* default: batches of <= 32 boards take the small-batch form (csrc/trunk15_wino3s.h) */
+#define APZ_TRUNK_WINOGRAD_BATCHED 4    /* ... the batched form for every batch size (the tests hold the two forms to bit equality) */
 int apz_test_select_trunk(apz_engine *e, int kind);
 int apz_kernel_time_ms(apz_engine *e, int kernel_class, float *out2);
 /* Enqueue `iters` forwards of n empty boards on the engine's stream and return without waiting (apz_sync waits).

@@ -304,7 +304,7 @@ def _net_with_trunk_kernel(kind, prm, n_blocks, batch):
     fused F(4x4,3x3) Winograd kernel (default); selected through the C ABI's test hook apz_test_select_trunk."""
     from alphapig_amd.policy_value_net import PolicyValueNet
     net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm)
-    net._ck(net.L.apz_test_select_trunk(net._h, {"ring": 0, "wino3": 3}[kind]))
+    net._ck(net.L.apz_test_select_trunk(net._h, {"ring": 0, "wino3": 3, "wino3-batched": 4}[kind]))
     return net
 
 
@@ -355,6 +355,32 @@ def test_trunk_kernels_agree_on_a_large_ragged_batch():
             np.testing.assert_array_equal(v2, outs[kind][1][perm])
         finally:
             net.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 32])
+def test_small_batch_trunk_kernel_gives_the_batched_kernels_bits(n):
+    """Batches of <= 32 boards (policy_value_fn: ONE board, policy_value_net_mxnet.py:261-280) run the trunk on
+    trunk15_wino3s_kernel (one board x 16 output channels per workgroup); larger ones on trunk15_wino3_kernel (board pair
+    x 64 channels).  Same transform, same accumulation order, same output formulas: the same bits -- here with the
+    batched kernel forced onto the small batch through the C ABI's test hook, and against the float64 oracle."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=15, style="bench")
+    _, planes = random_positions(n, 15, seed=500 + n)
+    small = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm)
+    batched = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm)
+    batched._ck(batched.L.apz_test_select_trunk(batched._h, 4))
+    a = small.forward_with_logits(planes)
+    b = batched.forward_with_logits(planes)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    small.forward_planes(planes)
+    batched.forward_planes(planes)
+    for layer in (1, 2, 6):
+        np.testing.assert_array_equal(small.layer_output(layer, n), batched.layer_output(layer, n))
+    o = net_ref.forward(prm, planes, "resnet", 3, np.float64)
+    np.testing.assert_allclose(a[0], o[0], rtol=0, atol=LOGIT_ATOL)
+    small.close()
+    batched.close()
 
 
 def test_small_batch_channel_groups_do_not_change_a_boards_bits():
