@@ -87,9 +87,40 @@ def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None):
     return res
 
 
+def config2_roofline(n=32):
+    """The six convolutions of the simple net at the batch BASELINE config 2 launches (32 boards = half of the 64
+    concurrent games): conv8_kernel's time per launch (HIP events over 200 back-to-back launches, apz_conv3x3_bench)
+    against the fp32 matrix pipe.  The dominant kernel of the configuration is the 256 -> 256 layer."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("simple", 8, 8, 9, 10, 128, seed=0, style="bench")
+    net = PolicyValueNet(8, 8, batch_size=n, model_params=prm, net_kind="simple")
+    planes = (np.random.RandomState(3).rand(n, 9, 8, 8) < 0.2).astype(np.float32)
+    net.forward_planes(planes)
+    chans = [9, 64, 64, 128, 128, 256, 256]
+    layers = []
+    for li in range(6):
+        ms = net.conv_bench(li, n, iters=200, warmup=20)
+        cin, cout = chans[li], chans[li + 1]
+        flops = 2.0 * n * cin * cout * 9 * 64
+        executed = n * (cout // 16) * ((cin + 3) // 4) * 9 * 4 * 2048.0      # MFMAs issued x 2048 flop
+        layers.append({"layer": "%d->%d" % (cin, cout), "us_per_launch": 1e3 * ms, "algorithmic_gflop": flops / 1e9,
+                       "executed_tflops": executed / ms / 1e9, "frac_of_fp32_mfma_peak": executed / ms / 1e9 / 157.3,
+                       "workgroups": n * (cout // 16)})
+    net.close()
+    dom = layers[-1]
+    return {"boards_per_launch": n, "layers": layers,
+            "roofline": {"kernel": "conv8_kernel<false,false>, 256 -> 256 at 8x8 (csrc/conv8_small.h): work item = board x 16 output "
+                                   "channels, contraction split over the four waves", "bound": "mfma",
+                         "achieved": dom["executed_tflops"], "peak": 157.3, "unit": "TFLOP/s", "frac": dom["frac_of_fp32_mfma_peak"],
+                         "us_per_launch": dom["us_per_launch"], "traffic": None,
+                         "note": "a 32-board launch is 512 workgroups = two per CU, one round: ~9 us of the launch are fixed costs "
+                                 "(launch, first input / weight round trip, reduction + store), the MFMA time alone is 16 us"}}
+
+
 def main():
     out = {"config1_pure_mcts_8x8_n100_cpu": config1()}
     out["config2_simple_net_8x8_n200_64games"] = gpu_config("simple", 8, 4, 200, 64, 6000)
+    out["config2_simple_net_8x8_n200_64games"]["kernels"] = config2_roofline(32)
     out["config3_resnet10_15x15_n400_1024games"] = gpu_config("resnet", 15, 5, 400, 1024, 400)
     out["config5_slice_resnet10_15x15_n1600_1024games"] = gpu_config("resnet", 15, 5, 1600, 1024, 2000,
                                                                      temp_schedule=[(0, 1.0), (30, 0.1)])
