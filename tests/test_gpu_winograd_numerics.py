@@ -13,7 +13,7 @@ and the direct-convolution kernel (APZ_TRUNK_KERNEL=ring: exact fp32 FMA chains,
 Tolerance: north_star's 1e-4 on the logits, relative to the logit scale when that exceeds 1 (a network whose
 logits are 1e6 cannot be held to 1e-4 absolute in fp32 by any kernel), with a 3x margin: the Winograd path must
 stay below (1e-4 / 3) * max(1, max|logit|) (exploding networks: see the end of the test).  The measured table is
-written to gpurun_out/ (committed as profiles/r02_winograd_numerics.json) and quoted in DESIGN.md.
+written to gpurun_out/ (committed as profiles/r03_winograd_numerics.json) and quoted in DESIGN.md.
 """
 import json
 import os
@@ -101,7 +101,7 @@ def test_winograd_trunk_keeps_a_3x_margin_under_stress():
         worst = max(worst, errs["wino3"][0], errs["wino3"][1])
     out = os.path.join(REPO, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r02_winograd_numerics.json"), "w") as f:
+    with open(os.path.join(out, "r03_winograd_numerics.json"), "w") as f:
         json.dump({"tolerance": TOL, "rows": rows, "worst_wino3": worst}, f, indent=1)
     for r in rows:
         print("%-14s %-7s scale %9.3g  wino3 %.2e / %.2e   ring %.2e / %.2e" % (
