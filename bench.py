@@ -349,6 +349,10 @@ def main():
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--profile-samples", type=int, default=20, help="... or more often, for at least this many timed forwards")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 REHEARSAL on a one-GPU box: every rank uses cuda:0 and the collectives run on gloo (RCCL refuses two "
+                         "ranks on one device).  Exercises the real evaluator under the multi-rank path; the line is marked "
+                         "invalid: the ranks share one GPU, so it is NOT a scaling measurement")
     ap.add_argument("--deadline-s", type=float, default=1800.0, help="self-spawned ranks: kill everything after this many seconds")
     ap.add_argument("--rank-silence-s", type=float, default=420.0,
                     help="self-spawned ranks: kill everything when no rank has written to its log for this long")
@@ -378,7 +382,9 @@ def main():
     ncpu = host_cpu_share()                                  # the JOB's CPU share (before this rank narrows its own mask)
     pinned = pin_rank_cpus(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))   # before any GPU call
     heartbeat("starting (cpu slice: %s)" % pinned)
-    rank, world, local = dist.init(backend="gloo" if args.plumbing_test else None)
+    rank, world, local = dist.init(backend="gloo" if (args.plumbing_test or args.rehearse_on_one_gpu) else None)
+    if args.rehearse_on_one_gpu:
+        local = 0
     heartbeat("process group up: rank %d of %d" % (rank, world))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
@@ -658,6 +664,9 @@ def main():
     if args.plumbing_test:
         line["valid"] = False
         line["data"] = "plumbing-test (CPU stand-in evaluator, 8 games per rank): NOT a measurement"
+    if args.rehearse_on_one_gpu:
+        line["valid"] = False
+        line["data"] = "REHEARSAL: %d ranks share ONE GPU, collectives on gloo: plumbing of the N > 1 path with the real evaluator, NOT a scaling measurement" % world
     if not args.no_extras and world == 1 and not args.plumbing_test:
         line["roofline_stem"] = stem_roofline(local)
         line["latency"] = latency_probe(local)

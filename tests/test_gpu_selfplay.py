@@ -184,6 +184,29 @@ def test_rccl_collectives_world_size_1():
     assert r.returncode == 0 and "rccl world_size=1 ok" in r.stdout, r.stdout[-2000:]
 
 
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2` through its own rank spawner with the REAL evaluator: both ranks on cuda:0, collectives on gloo
+    (RCCL refuses two ranks on one device; RCCL itself runs at world size 1 in the tests around this one).  What a one-GPU
+    box can show of configs[3]: sharded games, the tuple all-gather with real payloads, per-rank rates, one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--games", "256",
+           "--rehearse-on-one-gpu", "--no-extras", "--prewarm-s", "0.2", "--deadline-s", "600"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launcher"] == "self-spawned" and d["valid"] is False
+    assert len(d["per_rank_leaf_evals_per_s"]) == 2 and min(d["per_rank_leaf_evals_per_s"]) > 1000
+    assert d["leaf_evals_per_s"] > 2000 and d["config"]["games_per_gpu"] == 256 and d["roofline"]["frac"] > 0.0   # (the two ranks' kernels share the GPU)
+
+
 def test_rccl_training_pipeline_world_size_1():
     """configs[4]'s loop with the real HIP trainer and evaluator, collectives on RCCL (one rank): self-play ->
     all_gather_tuples -> policy_update (train_mxnet.py:194-240) -> flat weight broadcast -> load_device_params
