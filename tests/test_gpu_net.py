@@ -383,6 +383,32 @@ def test_small_batch_trunk_kernel_gives_the_batched_kernels_bits(n):
     batched.close()
 
 
+def test_prewarm_and_whole_forward_timing_hooks(resnet3):
+    """bench.py's measurement hooks through the C ABI: apz_prewarm queues dummy forwards of empty boards without waiting and
+    leaves the evaluator's answers alone; with profiling on, EVERY forward is bracketed as a whole (class "forward": the
+    numerator of gpu_busy_frac) while the per-kernel classes are sampled every k-th forward."""
+    net, prm = resnet3
+    _, planes = random_positions(9, 15, seed=321)
+    before = net.forward_planes(planes)
+    net.prewarm(64, 5)
+    net.sync()
+    after = net.forward_planes(planes)
+    np.testing.assert_array_equal(before[0], after[0])
+    np.testing.assert_array_equal(before[1], after[1])
+    net.set_profiling(2)
+    for _ in range(6):
+        net.forward_planes(planes)
+    net.prewarm(33, 4)
+    net.sync()
+    fwd_ms, fwd_n = net.kernel_time_ms("forward")
+    trunk_ms, trunk_n = net.kernel_time_ms("trunk")
+    net.set_profiling(False)
+    assert fwd_n == 10 and fwd_ms > 0                      # six real + four dummy forwards, every one timed
+    assert trunk_n == 5 * 6 and 0 < trunk_ms < fwd_ms      # every second forward sampled: 5 forwards x 6 trunk launches
+    with pytest.raises(Exception):
+        net.prewarm(10 ** 6, 1)                            # larger than max_batch: refused
+
+
 def test_small_batch_channel_groups_do_not_change_a_boards_bits():
     """The generic 3x3 convolution gives every board of a small batch to several workgroups of 64 output channels
     (launch_conv_t, BASELINE config 2's 32-board launches) and one workgroup per board in large batches; the 1x1 head
