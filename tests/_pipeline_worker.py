@@ -65,8 +65,36 @@ class TiltTrainer(object):
         return {k: v.copy() for k, v in self._p.items()}
 
 
+def main_real(out_dir):
+    """The same loop with the REAL evaluator and the REAL HIP trainer, every rank on cuda:0, collectives on gloo (a one-GPU box
+    cannot give each rank its own GPU, and RCCL refuses two ranks on one device): after the run every rank's evaluator
+    must answer like rank 0's -- the weights travelled through broadcast_params + set_params."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    rank, world, _ = dist.init(backend="gloo")
+    conf = {"board_width": 15, "board_height": 15, "n_in_row": 5, "learn_rate": 1e-3, "lr_multiplier": 1.0, "temp": 1.0,
+            "n_playout": 6, "c_puct": 5, "buffer_size": 100000, "batch_size": 32, "epochs": 2, "kl_targ": 0.02,
+            "check_freq": 1000, "game_batch_num": 3, "play_batch_size": 2, "pure_mcts_playout_num": 10,
+            "concurrent_games": 16, "n_blocks": 1, "n_filter": 128, "model_dir": os.path.join(out_dir, "models%d" % rank)}
+    pipe = TrainPipeline(conf, device=0, seed=5)
+    assert pipe.distributed and (pipe.rank, pipe.world) == (rank, world)
+    hist = pipe.run()
+    planes = (np.random.RandomState(9).rand(6, 9, 15, 15) < 0.2).astype(np.float32)
+    p, v = pipe.policy_value_net.policy_value(planes)
+    np.savez(os.path.join(out_dir, "real%d.npz" % rank), p=p, v=v)
+    res = {"rank": rank, "world": world, "updates": sum(1 for h in hist if "loss" in h),
+           "weight_broadcasts": getattr(pipe, "weight_broadcasts", 0), "buffer": len(pipe.data_buffer),
+           "has_trainer": getattr(pipe.policy_value_net, "_trainer", None) is not None}
+    with open(os.path.join(out_dir, "pipe%d.json" % rank), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    pipe.close()
+    dist.shutdown()
+
+
 def main():
     out_dir = sys.argv[1]
+    if len(sys.argv) > 2 and sys.argv[2] == "real":
+        return main_real(out_dir)
     rank, world, _ = dist.init(backend="gloo")
     conf = {"board_width": 8, "board_height": 8, "n_in_row": 4, "learn_rate": 2e-3, "lr_multiplier": 1.0, "temp": 1.0,
             "n_playout": 8, "c_puct": 5, "buffer_size": 100000, "batch_size": 16, "epochs": 2, "kl_targ": 0.02,

@@ -207,6 +207,30 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert d["leaf_evals_per_s"] > 2000 and d["config"]["games_per_gpu"] == 256 and d["roofline"]["frac"] > 0.0   # (the two ranks' kernels share the GPU)
 
 
+def test_two_rank_training_pipeline_with_the_real_trainer(tmp_path):
+    """configs[4]'s loop on TWO ranks with the real evaluator and the real HIP trainer (both ranks on cuda:0, collectives on
+    gloo -- see test_two_rank_bench_rehearsal_on_one_gpu): rank 0 trains, rank 1 never builds a trainer, and after the run
+    both evaluators give the same answers: the weights arrived through dist.broadcast_params."""
+    import json
+    import os
+    import random
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(28500 + random.randint(0, 1500)), os.path.join(here, "_pipeline_worker.py"), str(tmp_path), "real"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r0, r1 = (json.load(open(tmp_path / ("pipe%d.json" % k))) for k in (0, 1))
+    assert r0["updates"] >= 1 and r0["weight_broadcasts"] == r1["weight_broadcasts"] == r0["updates"]
+    assert r0["has_trainer"] and not r1["has_trainer"] and r1["buffer"] == 0 and r0["buffer"] > 0
+    a, b = np.load(tmp_path / "real0.npz"), np.load(tmp_path / "real1.npz")
+    np.testing.assert_allclose(a["p"], b["p"], rtol=0, atol=1e-6)     # rank 0: refreshed device to device; rank 1: folded on the host
+    np.testing.assert_allclose(a["v"], b["v"], rtol=0, atol=1e-6)
+
+
 def test_rccl_training_pipeline_world_size_1():
     """configs[4]'s loop with the real HIP trainer and evaluator, collectives on RCCL (one rank): self-play ->
     all_gather_tuples -> policy_update (train_mxnet.py:194-240) -> flat weight broadcast -> load_device_params
