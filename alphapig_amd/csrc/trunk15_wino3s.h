@@ -20,11 +20,16 @@
 // identically.  tests/test_gpu_net.py holds the two kernels to bit equality across batch shapes.
 //
 // Workgroup (board, cot, half), 256 threads, per chunk of 8 input channels (16 chunks, one barrier each):
-//   all        staging: thread -> plane tid >> 5, two 16-byte pieces, global -> registers (a chunk ahead) -> raw LDS tile
 //   waves 0-1  MFMA: wave w = positions 18 half + 9 w .. + 8, 2 k-steps x 9 MFMAs over V[chunk g]; weights in
-//              WinoPackSmall order (three coalesced 16-byte loads per k-step), requested a chunk ahead
+//              WinoPackSmall order (two coalesced 16-byte loads + one 4-byte load per k-step); and ALL the staging:
+//              thread -> plane, four 16-byte pieces, global -> registers -> raw LDS tile.  Planes and weights are
+//              requested FOUR chunks ahead (register rings): a chunk is ~0.3 us of work, a round trip 1-2 us
 //   waves 2-3  transform of chunk g + 1: thread = (channel, tile), the `half` rows of its 6x6 patch -> 18 values of
-//              V[pos 18][ch 8][tile 16]
+//              V[pos 18][ch 8][tile 16]; LDS only, no global load
+// The two roles run SEPARATE loops with the same barriers.  What that is for (profiles/r03_latency.md): with global loads
+// on one side of a wave-role branch hipcc sizes every vmcnt wait for the side without them, and with 16-byte loads that
+// leave dead registers the allocator reuses those while the load is in flight -- both made every chunk wait out a round
+// trip (15.9 us per layer, 11 of them in this loop; 13.6 us after).
 // Epilogue: the 18 x 16 x 16 accumulators through LDS (M aliases the two V buffers); thread = (channel, tile) forms its row
 // partial (wino3's lo = (h0+h1+h2, h1-h2, h1+h2) or hi = (h3+h4, h3-h4, h5) per output column: 12 floats) and writes it to
 // a global slab.  The two halves of a (board, cot) meet through an in-launch reduction (cdna_hip_programming.md, "In-launch
@@ -76,24 +81,30 @@ __global__ __launch_bounds__(256) void trunk15_wino3s_kernel(const float* __rest
     const int bd = blockIdx.x >> 4, half = (blockIdx.x >> 3) & 1, cot = blockIdx.x & 7;
     if (bd >= n) return;                        // (uniform)
 
-    // ---- staging role
-    const int st_p = tid >> 5, st_k = tid & 31, st_k2 = (st_k + 32 < 60) ? st_k + 32 : st_k;
-    // A chunk's interval is ~0.4 us of work, an L2 / HBM round trip is 1-2 us: planes and weights are requested FOUR
-    // chunks ahead into register rings (slot = chunk & 3; the loop is unrolled by four so that slots are static).  With one
-    // chunk of distance every interval waited out a round trip: 17 us per layer whatever the decomposition.
-    f32x4 rg[4][2];
+    // ---- staging role (the MFMA waves: threads 0..127; ALL global loads of the workgroup are theirs, see below): thread ->
+    // plane tid >> 4, pieces (tid & 15) + 16 i, i = 0..3 (of 60; the last clamps)
+    // A chunk's interval is ~0.3 us of work, an L2 / HBM round trip is 1-2 us: planes and weights are requested FOUR chunks
+    // ahead into register rings (slot = chunk & 3; the loops are unrolled by four so that slots are static).
+    const int st_p = (tid >> 4) & 7, st_k0 = tid & 15;
+    f32x4 rg[4][4];
     auto raw_fetch = [&](auto SLOT, int g) {
         constexpr int sl = decltype(SLOT)::value;
         g = g < T::NCHUNK ? g : T::NCHUNK - 1;
         const float* src = in + ((size_t)bd * T::C + g * T::CK + st_p) * T::GPLANE;
-        rg[sl][0] = *reinterpret_cast<const f32x4*>(src + st_k * 4);
-        rg[sl][1] = *reinterpret_cast<const f32x4*>(src + st_k2 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = st_k0 + 16 * i < 60 ? st_k0 + 16 * i : st_k0 + 32;
+            rg[sl][i] = *reinterpret_cast<const f32x4*>(src + k * 4);
+        }
     };
     auto raw_store = [&](auto SLOT, int par) {
         constexpr int sl = decltype(SLOT)::value;
         float* dst = rawb + par * T::RAW_FLOATS + T::RFRONT + st_p * T::RPS;
-        *reinterpret_cast<f32x4*>(dst + (st_k >> 2) * T::RROW + (st_k & 3) * 4) = rg[sl][0];
-        *reinterpret_cast<f32x4*>(dst + (st_k2 >> 2) * T::RROW + (st_k2 & 3) * 4) = rg[sl][1];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = st_k0 + 16 * i < 60 ? st_k0 + 16 * i : st_k0 + 32;
+            *reinterpret_cast<f32x4*>(dst + (k >> 2) * T::RROW + (k & 3) * 4) = rg[sl][i];
+        }
     };
     // ---- transform role (waves 2, 3): unit = (channel, tile); the workgroup's row half ph = half
     const bool producer = wave >= 2;
@@ -146,15 +157,20 @@ __global__ __launch_bounds__(256) void trunk15_wino3s_kernel(const float* __rest
     // ---- weights of MFMA wave w (positions 18 half + 9 w .. + 8): WinoPackSmall, three coalesced 16-byte loads per k-step
     const int mw = wave & 1;
     const float* ubase = upk + (size_t)((cot * 4 + 2 * half + mw) * 32) * WinoPackSmall::STEP + lane * 4;
-    f32x4 uq[4][2][3];
+    // (value 8 of a k-step as ONE float: a 16-byte load would leave three dead registers per k-step, the allocator reuses
+    // them for temporaries, and every such write then waits for the load still in flight -- the wait of a recent load)
+    f32x4 uq[4][2][2];
+    float u8[4][2];
     auto uload = [&](auto SLOT, int g) {
         constexpr int sl = decltype(SLOT)::value;
         g = g < T::NCHUNK ? g : T::NCHUNK - 1;
 #pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int v = 0; v < 3; v++)
-                uq[sl][s][v] = *reinterpret_cast<const f32x4*>(ubase + (size_t)(2 * g + s) * WinoPackSmall::STEP + v * 256);
+        for (int s = 0; s < 2; s++) {
+            const float* up = ubase + (size_t)(2 * g + s) * WinoPackSmall::STEP;
+            uq[sl][s][0] = *reinterpret_cast<const f32x4*>(up);
+            uq[sl][s][1] = *reinterpret_cast<const f32x4*>(up + 256);
+            u8[sl][s] = up[512];
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -164,53 +180,71 @@ __global__ __launch_bounds__(256) void trunk15_wino3s_kernel(const float* __rest
     f32x4 acc[9];
 #pragma unroll
     for (int m = 0; m < 9; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    raw_fetch(I0{}, 0);
-    raw_fetch(I1{}, 1);
-    raw_fetch(I2{}, 2);
-    raw_fetch(I3{}, 3);
-    if (!producer) {
+    // Role-specific code paths from here to the epilogue, with the same barriers in both: the transform waves touch LDS
+    // only; every global load sits in the MFMA waves' path, unconditionally, so that hipcc's vmcnt bookkeeping is exact
+    // (with loads on one side of a wave-role branch it sized the staging wait for the side WITHOUT them -- vmcnt(7) -- and
+    // the MFMA waves waited for all but their seven youngest loads at every chunk: 0.7 us per chunk for 0.3 us of work).
+    const float* vrd = vb + (9 * mw) * T::VPOS + q * 16 + j;
+#ifndef APZ_W3S_CHUNKS
+#define APZ_W3S_CHUNKS T::NCHUNK        /* (measurement builds shorten the loop: what a layer costs without it) */
+#endif
+    if (producer) {
+        for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 1024) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                        // zero halo in place
+        __syncthreads();                        // raw[0] = chunk 0
+        transform(0);
+        __syncthreads();                        // V[0] = chunk 0, raw[1] = chunk 1
+        for (int g = 0; g < APZ_W3S_CHUNKS; g++) {
+            if (g + 1 < T::NCHUNK) transform((g & 1) ^ 1);       // raw[(g + 1) & 1] -> V[(g + 1) & 1]
+            __syncthreads();
+        }
+    } else {
+        raw_fetch(I0{}, 0);
+        raw_fetch(I1{}, 1);
+        raw_fetch(I2{}, 2);
+        raw_fetch(I3{}, 3);
         uload(I0{}, 0);
         uload(I1{}, 1);
         uload(I2{}, 2);
         uload(I3{}, 3);
-    }
-    for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 1024) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();                            // zero halo in place
-    raw_store(I0{}, 0);
-    raw_fetch(I0{}, 4);
-    __syncthreads();                            // raw[0] = chunk 0
-    raw_store(I1{}, 1);
-    raw_fetch(I1{}, 5);
-    if (producer) transform(0);
-    __syncthreads();                            // V[0] = chunk 0, raw[1] = chunk 1
-    // interval g: everybody stages chunk g + 2 into raw[g & 1] (its chunk g was transformed in the interval before) and
-    // requests chunk g + 6; the MFMA waves work on V[g & 1] and then request the weights of chunk g + 4; the transform
-    // waves turn raw[(g + 1) & 1] into V[(g + 1) & 1].  One barrier per chunk.
-    const float* vrd = vb + (9 * mw) * T::VPOS + q * 16 + j;
-    auto chunk = [&](auto SLOT, int g) {        // SLOT = g & 3
-        constexpr int sl = decltype(SLOT)::value;
-        using RS = std::integral_constant<int, (sl + 2) & 3>;
-        const int par = g & 1;
-        raw_store(RS{}, par);                   // chunk g + 2 (past the end: a harmless re-store of chunk 15)
-        raw_fetch(RS{}, g + 6);
-        if (producer) {
-            if (g + 1 < T::NCHUNK) transform(par ^ 1);
-        } else {
+        for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 1024) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                        // zero halo in place
+        raw_store(I0{}, 0);
+        raw_fetch(I0{}, 4);
+        __syncthreads();                        // raw[0] = chunk 0
+        raw_store(I1{}, 1);
+        raw_fetch(I1{}, 5);
+        __syncthreads();                        // V[0] = chunk 0, raw[1] = chunk 1
+        // interval g: stage chunk g + 2 into raw[g & 1] (its chunk g was transformed in the interval before), request chunk
+        // g + 6, MFMAs over V[g & 1], then request the weights of chunk g + 4.  One barrier per chunk.
+        auto chunk = [&](auto SLOT, int g) {    // SLOT = g & 3
+            constexpr int sl = decltype(SLOT)::value;
+            using RS = std::integral_constant<int, (sl + 2) & 3>;
+            const int par = g & 1;
+            raw_store(RS{}, par);               // chunk g + 2 (past the end: a harmless re-store of chunk 15)
+            raw_fetch(RS{}, g + 6);
             const float* vp = vrd + par * T::V_FLOATS;
+            float bo[2][9];
 #pragma unroll
             for (int s = 0; s < 2; s++)
 #pragma unroll
-                for (int m = 0; m < 9; m++)
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[sl][s][m >> 2][m & 3], vp[m * T::VPOS + s * 64], acc[m], 0, 0, 0);
+                for (int m = 0; m < 9; m++) bo[s][m] = vp[m * T::VPOS + s * 64];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int m = 0; m < 9; m++) {
+                    const float a = m < 8 ? uq[sl][s][m >> 2][m & 3] : u8[sl][s];
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bo[s][m], acc[m], 0, 0, 0);
+                }
             uload(SLOT, g + 4);
+            __syncthreads();
+        };
+        for (int g = 0; g < APZ_W3S_CHUNKS; g += 4) {
+            chunk(I0{}, g);
+            chunk(I1{}, g + 1);
+            chunk(I2{}, g + 2);
+            chunk(I3{}, g + 3);
         }
-        __syncthreads();
-    };
-    for (int g = 0; g < T::NCHUNK; g += 4) {
-        chunk(I0{}, g);
-        chunk(I1{}, g + 1);
-        chunk(I2{}, g + 2);
-        chunk(I3{}, g + 3);
     }
     // ---- epilogue, part 1: M[pos 18][ch 16][tile 16] through LDS; thread (channel c, tile) forms its row partial
     // (the chunk loop's last barrier: every wave's MFMAs over V are done)
