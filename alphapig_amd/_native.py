@@ -87,6 +87,11 @@ def host():
         "apzh_stats": (C.c_int, [vp, C.c_int, i64p]),
         "apzh_pool_info": (C.c_int, [vp, i64p]),
         "apzh_pure_get_move": (C.c_int, [vp, C.c_int, u32p, i32p, i32p, i64p, f64p, C.c_int, i32p]),
+        "apzh_mt_seed": (C.c_int, [C.c_uint32, u32p, i32p]),
+        "apzh_np_sum": (C.c_double, [f64p, C.c_int64]),
+        "apzh_root_sample": (C.c_int, [C.c_int, C.c_int, f64p, i32p, i32p, C.c_double, C.c_double, C.c_int, u32p, i32p,
+                                       i32p, f64p, f64p, i32p, C.c_int]),
+        "apzh_pretouch_limit_gb": (C.c_double, [C.c_double, C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -102,7 +107,8 @@ HOST_SYMBOLS = ["apzh_last_error", "apzh_version", "apzh_create", "apzh_destroy"
                 "apzh_advance", "apzh_feed", "apzh_feed_sparse", "apzh_pending_path", "apzh_playouts_done",
                 "apzh_set_playouts_done", "apzh_set_n_playout", "apzh_node_children", "apzh_set_prior_mode",
                 "apzh_root_visits_dense", "apzh_update_with_move", "apzh_play_move", "apzh_stats",
-                "apzh_pool_info", "apzh_pure_get_move"]
+                "apzh_pool_info", "apzh_pure_get_move", "apzh_mt_seed", "apzh_np_sum", "apzh_root_sample",
+                "apzh_pretouch_limit_gb"]
 
 HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create", "apz_destroy",
                "apz_param_count", "apz_param_name", "apz_param_size", "apz_load_weights", "apz_forward",

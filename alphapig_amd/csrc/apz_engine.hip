@@ -133,7 +133,8 @@ struct apz_engine {
     hipStream_t scratch_stream = nullptr;          // the stream of the last entry point that may have used the scratch buffers
     bool scratch_stream_valid = false;
     float* w3s_slabs = nullptr;              // trunk15_wino3s_kernel: row partials of the position halves
-    unsigned* w3s_tickets = nullptr;         // ... and the pairs' ticket counters (zeroed once; every launch adds two to each it uses)
+    unsigned* w3s_tickets = nullptr;         // ... and the pairs' ticket words (each launch exchanges its epoch in: trunk15_wino3s.h)
+    unsigned w3s_epoch = 0;                  // last epoch handed out; never 0, never repeated between two memsets of the words
     bool no_small_trunk = false;             // apz_test_select_trunk(APZ_TRUNK_WINOGRAD_BATCHED): tests compare the two forms
     int trunk_kernel = APZ_TRUNK_WINOGRAD;   // or APZ_TRUNK_DIRECT (trunk15_ring_kernel): apz_test_select_trunk, tests only
     // profiling
@@ -375,14 +376,19 @@ int launch_wino3_t(apz_engine* e, int attr_slot, const float* in, const float* u
     }
     if (upk_small && n <= apz::Wino3S::MAX_BOARDS && !e->no_small_trunk) {
         // the latency path: sixteen workgroups per board (16 output channels x half the positions), the same bits
-        // (csrc/trunk15_wino3s.h); the halves meet through global slabs + ticket counters that are never reset
+        // (csrc/trunk15_wino3s.h); the halves meet through global slabs + ticket words keyed by a per-launch epoch
         if (!e->w3s_slabs) {
             HIP_TRY(hipMalloc((void**)&e->w3s_slabs, apz::Wino3S::slab_floats() * sizeof(float)));
             HIP_TRY(hipMalloc((void**)&e->w3s_tickets, apz::Wino3S::counters() * sizeof(unsigned)));
-            HIP_TRY(hipMemset(e->w3s_tickets, 0, apz::Wino3S::counters() * sizeof(unsigned)));
+            e->w3s_epoch = 0;
+        }
+        if (++e->w3s_epoch == 0 || e->w3s_epoch == 1) {
+            // first launch, or the 32-bit epoch wrapped: zero the words ON THE LAUNCH STREAM (ordered before the kernel)
+            e->w3s_epoch = 1;
+            HIP_TRY(hipMemsetAsync(e->w3s_tickets, 0, apz::Wino3S::counters() * sizeof(unsigned), e->stream));
         }
         hipLaunchKernelGGL((apz::trunk15_wino3s_kernel<RESID, RELU>), dim3(n * 16), dim3(256), apz::Wino3S::LDS_BYTES, e->stream, in,
-                           upk_small, bias, RESID ? resid : nullptr, out, n, e->w3s_slabs, e->w3s_tickets);
+                           upk_small, bias, RESID ? resid : nullptr, out, n, e->w3s_slabs, e->w3s_tickets, e->w3s_epoch);
         HIP_TRY(hipGetLastError());
         return APZ_OK;
     }

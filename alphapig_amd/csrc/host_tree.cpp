@@ -130,6 +130,91 @@ struct MT {
     }
 };
 
+// NumPy's LEGACY distributions (np.random.RandomState: what `np.random.dirichlet` / `np.random.choice` of
+// mcts_alphaZero.py:198-201 draw through), restated from their published algorithms: standard exponential by
+// inversion, Gaussian by the polar method with the second value cached in the generator state, standard gamma by
+// Marsaglia-Tsang (shape >= 1) / the Ahrens-Dieter style rejection for shape < 1.  log / pow / sqrt are the C library's,
+// which is what NumPy calls for scalars.
+struct LegacyRng {
+    MT mt;
+    int32_t *has_gauss;
+    double *gauss;
+    double dbl() { return mt.next_double(); }
+    double standard_exponential() { return -std::log(1.0 - dbl()); }
+    double gauss_next() {
+        if (*has_gauss) {
+            const double tmp = *gauss;
+            *gauss = 0.0;
+            *has_gauss = 0;
+            return tmp;
+        }
+        double f, x1, x2, r2;
+        do {
+            x1 = 2.0 * dbl() - 1.0;
+            x2 = 2.0 * dbl() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        f = std::sqrt(-2.0 * std::log(r2) / r2);
+        *gauss = f * x1;
+        *has_gauss = 1;
+        return f * x2;
+    }
+    double standard_gamma(double shape) {
+        if (shape == 1.0) return standard_exponential();
+        if (shape == 0.0) return 0.0;
+        if (shape < 1.0) {
+            for (;;) {
+                const double U = dbl();
+                const double V = standard_exponential();
+                if (U <= 1.0 - shape) {
+                    const double X = std::pow(U, 1.0 / shape);
+                    if (X <= V) return X;
+                } else {
+                    const double Y = -std::log((1.0 - U) / shape);
+                    const double X = std::pow(1.0 - shape + shape * Y, 1.0 / shape);
+                    if (X <= (V + Y)) return X;
+                }
+            }
+        }
+        const double b = shape - 1.0 / 3.0;
+        const double c = 1.0 / std::sqrt(9.0 * b);
+        for (;;) {
+            double X, V;
+            do {
+                X = gauss_next();
+                V = 1.0 + c * X;
+            } while (V <= 0.0);
+            V = V * V * V;
+            const double U = dbl();
+            if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return b * V;
+            if (std::log(U) < 0.5 * X * X + b * (1.0 - V + std::log(V))) return b * V;
+        }
+    }
+};
+
+// np.sum of a contiguous float64 vector: NumPy's pairwise summation (blocks of <= 128 elements summed through eight
+// running sums, larger inputs halved at multiples of eight).  tests/test_host_sampler.py holds it to np.sum bit for bit.
+double np_pairwise_sum(const double *a, long n) {
+    if (n < 8) {
+        double res = -0.0;
+        for (long i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; k++) r[k] = a[k];
+        long i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 }  // namespace
 
 struct apzh_pool {
@@ -440,9 +525,11 @@ apzh_pool *apzh_create(const apzh_config *cfg) {
     // 15x15 at n_playout = 400 are 8.7 GB): first-touch page faults cost more than the tree work itself
     // (feed median 0.35 ms against 0.15 ms once the pages exist) and would otherwise sit in the first
     // two searches of every slot -- most of a short benchmark window.
-    // The limit follows the memory this process may really use -- half of min(MemAvailable, cgroup memory.max),
-    // at most 96 GB -- so that the competition-strength slice (BASELINE config 5: n_playout = 1600, 1024 games,
+    // The limit follows the memory this process may really use -- its share of half of min(MemAvailable, cgroup
+    // memory.max), at most 96 GB (apzh_pretouch_limit_gb) -- so that the competition-strength slice (BASELINE config 5: n_playout = 1600, 1024 games,
     // 31 GB of arenas) is touched up front as well instead of faulting its pages in inside the first searches.
+    // All ranks of a node start together and each reads the same MemAvailable: the share is divided by the number of
+    // ranks on this node (LOCAL_WORLD_SIZE, as torchrun and bench.py's own rank spawner export it).
     double limit_gb = 16.0;
     {
         double avail_gb = 0.0;
@@ -459,7 +546,9 @@ apzh_pool *apzh_create(const apzh_config *cfg) {
             if (fscanf(f, "%llu", &b) == 1 && (avail_gb == 0.0 || (double)b / 1e9 < avail_gb)) avail_gb = (double)b / 1e9;
             fclose(f);
         }
-        if (avail_gb > 0.0) limit_gb = std::min(96.0, std::max(4.0, 0.5 * avail_gb));
+        int local_world = 1;
+        if (const char *s = getenv("LOCAL_WORLD_SIZE")) local_world = atoi(s);
+        if (avail_gb > 0.0) limit_gb = apzh_pretouch_limit_gb(avail_gb, local_world);
     }
     if (const char *s = getenv("APZ_HOST_PRETOUCH_GB")) limit_gb = atof(s);
     const double total_gb = 2.0 * (double)cfg->n_games * (double)cap * (double)Arena::bytes_per_node() / 1e9;
@@ -857,6 +946,93 @@ int apzh_pure_get_move(apzh_pool *p, int gi, uint32_t *mt_key624, int32_t *mt_po
     int move = t.action[best];
     t.reset_root();                                                     // update_with_move(-1)
     return move;
+}
+
+double apzh_pretouch_limit_gb(double avail_gb, int local_world) {
+    if (local_world < 1) local_world = 1;
+    // half of what is available, split between the ranks of this node; never more than 96 GB per rank, and at least
+    // 4 GB per rank as long as the ranks' floors together still fit into that half
+    const double share = 0.5 * avail_gb / (double)local_world;
+    return std::min(96.0, std::max(std::min(4.0, share * 2.0), share));
+}
+
+int apzh_mt_seed(uint32_t seed, uint32_t *key624, int32_t *pos) {
+    if (!key624 || !pos) return fail(APZH_E_ARG, "null rng state");
+    // np.random.RandomState(seed) / np.random.seed(seed) for an integer seed: Knuth's initialiser, position 624
+    key624[0] = seed;
+    for (int i = 1; i < 624; i++) key624[i] = 1812433253u * (key624[i - 1] ^ (key624[i - 1] >> 30)) + (uint32_t)i;
+    *pos = 624;
+    return APZH_OK;
+}
+
+double apzh_np_sum(const double *a, int64_t n) { return (a && n > 0) ? np_pairwise_sum(a, (long)n) : 0.0; }
+
+int apzh_root_sample(int g, int hw, const double *e_flat, const int32_t *acts_flat, const int32_t *counts, double alpha,
+                     double eps, int with_noise, uint32_t *keys, int32_t *pos, int32_t *has_gauss, double *gauss,
+                     double *pi_out, int32_t *moves_out, int n_threads) {
+    if (g < 0 || hw <= 0 || !e_flat || !acts_flat || !counts || !keys || !pos || !has_gauss || !gauss || !moves_out)
+        return fail(APZH_E_ARG, "null argument");
+    std::vector<int64_t> start((size_t)g + 1, 0);
+    for (int i = 0; i < g; i++) {
+        if (counts[i] <= 0 || counts[i] > hw) return fail(APZH_E_ARG, "a row without children");
+        start[i + 1] = start[i] + counts[i];
+    }
+#ifdef _OPENMP
+    const int nt = n_threads > 0 ? n_threads : 1;
+#pragma omp parallel num_threads(nt) if (g > 4 && nt > 1)
+#endif
+    {
+        std::vector<double> probs((size_t)hw), cdf((size_t)hw);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int i = 0; i < g; i++) {
+            const int k = counts[i];
+            const double *e = e_flat + start[i];
+            const int32_t *acts = acts_flat + start[i];
+            // probs = e / np.sum(e)                                 (mcts_alphaZero.py:13-16, the tail of softmax)
+            const double s = np_pairwise_sum(e, k);
+            for (int j = 0; j < k; j++) probs[j] = e[j] / s;
+            if (pi_out) {
+                double *pi = pi_out + (size_t)i * hw;
+                for (int j = 0; j < hw; j++) pi[j] = 0.0;
+                for (int j = 0; j < k; j++) pi[acts[j]] = probs[j];
+            }
+            LegacyRng rng{MT{keys + (size_t)i * 624, pos + i}, has_gauss + i, gauss + i};
+            if (with_noise) {
+                // noise = dirichlet(alpha * ones(k)): k standard gammas, normalised by the reciprocal of their sum
+                double acc = 0.0;
+                for (int j = 0; j < k; j++) {
+                    cdf[j] = rng.standard_gamma(alpha);
+                    acc += cdf[j];
+                }
+                const double invacc = 1.0 / acc;
+                // p = (1 - eps) * probs + eps * noise               (:198-200; no fused multiply-add: -ffp-contract=off)
+                const double keep = 1.0 - eps;
+                for (int j = 0; j < k; j++) {
+                    const double noise = cdf[j] * invacc;
+                    const double a = keep * probs[j], b = eps * noise;
+                    probs[j] = a + b;
+                }
+            }
+            // choice(acts, p): cdf = cumsum(p); cdf /= cdf[-1]; first index with cdf > one uniform double
+            double run = 0.0;
+            for (int j = 0; j < k; j++) {
+                run = j == 0 ? probs[0] : run + probs[j];
+                cdf[j] = run;
+            }
+            const double last = cdf[k - 1];
+            for (int j = 0; j < k; j++) cdf[j] /= last;
+            const double u = rng.dbl();
+            int lo = 0, hi = k;                                      // searchsorted(side='right')
+            while (lo < hi) {
+                const int mid = lo + (hi - lo) / 2;
+                if (u < cdf[mid]) hi = mid; else lo = mid + 1;
+            }
+            moves_out[i] = acts[lo < k ? lo : k - 1];
+        }
+    }
+    return APZH_OK;
 }
 
 }  // extern "C"

@@ -86,7 +86,7 @@ struct Wino3 {
 __device__ float apz_wino3_dbg[8 * 4 * 2 * 64 * 4];   // [wave][r][sent/received][lane][4]: P2 of the exchange
 #endif
 #ifdef APZ_WINO3_STAMPS
-// cycle accounting (tools/wino_ablate.hip): [workgroup 4][wave 8][phase 8], read with hipMemcpyFromSymbol
+// cycle accounting (-DAPZ_WINO3_STAMPS build of tools/wino3_bench.hip): [workgroup 4][wave 8][phase 8], read with hipMemcpyFromSymbol
 __device__ unsigned long long apz_wino3_stamps[4 * 8 * 8];
 #endif
 

@@ -35,8 +35,11 @@
 // a global slab.  The two halves of a (board, cot) meet through an in-launch reduction (cdna_hip_programming.md, "In-launch
 // split-K reduction", counter form): every wave drains its stores, one lane issues an agent-scope release and draws a
 // ticket from the pair's counter; the workgroup that draws the second ticket issues an agent-scope acquire, reads the
-// other half's slab and finishes the 4x4 output patches.  The counters are never reset: a launch adds exactly two to
-// each, so the second arriver is the one that reads an odd value (they start at zero, hipMemset at allocation).
+// other half's slab and finishes the 4x4 output patches.  Ticket = an atomic EXCHANGE of the launch's `epoch` (a number
+// the engine never hands out twice, never 0) into the pair's word: the second arriver is the one that gets the epoch back.
+// Nothing depends on what earlier launches left behind (round 3 counted arrivals and told the second by an odd value: one
+// launch that died half way would have flipped every later result on that engine); the words start at zero, set by a
+// stream-ordered memset at allocation and again whenever the epoch counter wraps.
 // Blocks b and b + 8 (the two halves) are dealt to the same XCD by the dispatcher as observed -- speed only.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -69,7 +72,7 @@ template <bool RESID, bool RELU = true>
 __global__ __launch_bounds__(256) void trunk15_wino3s_kernel(const float* __restrict__ in, const float* __restrict__ upk /* WinoPackSmall */,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ resid, float* __restrict__ out,
-                                                             int n, float* __restrict__ slabs, unsigned* __restrict__ tickets) {
+                                                             int n, float* __restrict__ slabs, unsigned* __restrict__ tickets, unsigned epoch) {
     using T = Wino3S;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* rawb = lds;                          // [2][RAW_FLOATS]
@@ -299,12 +302,13 @@ __global__ __launch_bounds__(256) void trunk15_wino3s_kernel(const float* __rest
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (keep: the fence's own wait can be dropped by the compiler)
-        const unsigned old = __hip_atomic_fetch_add(tickets + pairi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old & 1u) {
+        const unsigned old = __hip_atomic_exchange(tickets + pairi, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned second = old == epoch ? 1u : 0u;     // the other half of this launch has been here
+        if (second) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        *lflag = old & 1u;
+        *lflag = second;
     }
     __syncthreads();
     if (*lflag == 0u) return;                   // first arriver of the pair: done (uniform)

@@ -33,7 +33,11 @@ def init(backend=None, device_index=None, force=False):
         if backend == "nccl":
             torch.cuda.set_device(local if device_index is None else device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # Ranks legitimately sit in a collective for a long time while rank 0 runs an arena evaluation or an SGF phase
+        # (pipeline.py); the backend default (10 minutes on NCCL / RCCL) would let the watchdog kill such a job.
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("APZ_DIST_TIMEOUT_S", "7200")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
 
@@ -116,6 +120,17 @@ def all_gather_floats(x):
     return [float(v) for v in out.cpu()]
 
 
+def group_info():
+    """What the live process group says about itself (bench.py prints it): backend (nccl == RCCL on ROCm), world size
+    as the BACKEND sees it, this rank.  None without a process group."""
+    if not _ACTIVE:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return None
+    return {"backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()), "rank": int(dist.get_rank())}
+
+
 def rank_world():
     """(rank, world) of this process: from the live process group, else from the launcher's environment, else (0, 1)."""
     if _ACTIVE:
@@ -171,10 +186,12 @@ def broadcast_floats(values, src=0):
     return [float(v) for v in t.cpu()]
 
 
-def all_gather_tuples(codes, pis, zs):
+def all_gather_tuples(codes, pis, zs, consumer=None):
     """codes uint8 [T, S], pis float32 [T, HW], zs float32 [T] of this rank ->
     the concatenation over ranks in rank order (every rank gets everything).
-    Variable T per rank: counts are gathered first, payloads are padded to max T."""
+    Variable T per rank: counts are gathered first, payloads are padded to max T.
+    consumer = r: only rank r needs the result (the training pipeline's replay buffer lives on rank 0): the other
+    ranks take part in the collective but skip the device -> host copy and the unpacking and get empty arrays."""
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     pis = np.ascontiguousarray(pis, dtype=np.float32)
     zs = np.ascontiguousarray(zs, dtype=np.float32).reshape(-1)
@@ -203,6 +220,8 @@ def all_gather_tuples(codes, pis, zs):
     send = torch.from_numpy(buf).to(dev)
     recv = torch.empty((world * tmax, row), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send)
+    if consumer is not None and dist.get_rank() != int(consumer):
+        return codes[:0], pis[:0], zs[:0]
     out = recv.cpu().numpy().reshape(world, tmax, row)
     keep = np.concatenate([out[r, :counts[r]] for r in range(world)])
     g_codes = np.ascontiguousarray(keep[:, :S])

@@ -152,7 +152,7 @@ class TrainPipeline(object):
             codes = np.concatenate([e.codes for e in eps])
             pis = np.concatenate([e.pis for e in eps]).astype(np.float32)
             zs = np.concatenate([e.zs for e in eps]).astype(np.float32)
-            codes, pis, zs = dist.all_gather_tuples(codes, pis, zs)          # THE exchange of the round (RCCL all-gather)
+            codes, pis, zs = dist.all_gather_tuples(codes, pis, zs, consumer=None if self.keep_replica_buffers else 0)   # THE exchange of the round (RCCL all-gather)
             self.last_gathered = len(zs)
             if self.rank != 0 and not self.keep_replica_buffers:
                 return

@@ -11,6 +11,7 @@ AMD GPU.  Extra (non-reference) entry points used by the batched engine: `evalua
 (compact leaf codes, planes encoded on device) and `forward_planes`.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -39,6 +40,7 @@ class PolicyValueNet(object):
         kind = {"resnet": 0, "simple": 1}[net_kind]
         cfg = ApzConfig(self.board_height, self.board_width, self.channelnum, self._n_filter, self._n_blocks,
                         kind, self.batchsize, int(device))
+        self._fn_lock = threading.Lock()      # policy_value_fn: one submit + wait pair on the latency slot at a time
         self._h = self.L.apz_create(C.byref(cfg))
         if not self._h:
             raise EvaluatorError("apz_create failed: %s" % self.L.apz_last_error().decode())
@@ -204,8 +206,11 @@ class PolicyValueNet(object):
                                                    as_ptr(vals[s:s + k], C.c_float)))
         return probs, vals
 
-    # ---- stream-ordered slots: a second batch queued while the first runs (selfplay pipeline)
-    n_slots = 4
+    # ---- stream-ordered slots: a second batch queued while the first runs (selfplay pipeline).  The engine has
+    # APZ_MAX_SLOTS = 4 of them; SelfPlayEngine's pipeline groups use slots 0 .. n_slots - 1, the last one is reserved for
+    # policy_value_fn so that a human-play / serving front end and a self-play engine can share one net.
+    n_slots = 3
+    latency_slot = 3
 
     def evaluate_codes_slot(self, slot, codes):
         """submit + wait on one slot; safe to call from one host thread per slot."""
@@ -276,7 +281,10 @@ class PolicyValueNet(object):
         codes = getattr(board, "position_codes", None)
         if codes is not None and getattr(board, "width", None) == self.board_width and \
                 getattr(board, "height", None) == self.board_height:
-            probs, vals = self.evaluate_codes_slot(self.n_slots - 1, codes()[None])
+            # apz_wait takes no engine lock (it only waits on the slot's event), so two threads calling policy_value_fn on
+            # one net must not interleave their submit / wait pairs on the shared slot: serialise them here
+            with self._fn_lock:
+                probs, vals = self.evaluate_codes_slot(self.latency_slot, codes()[None])
         else:
             state = np.ascontiguousarray(board.current_state(), dtype=np.float32)
             probs, vals = self.forward_planes(state.reshape(1, self.channelnum, self.board_height, self.board_width))

@@ -25,6 +25,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from .game_ai import draw_forced_opening, one_hot_pi
+from .rootsample import LegacyRngBank, sample_moves
 from .treepool import TreePool, NEED_EVAL, MOVE_READY
 
 Episode = collections.namedtuple("Episode", "index moves movers codes pis zs winner")
@@ -79,11 +80,16 @@ class SelfPlayEngine(object):
         self.pipeline = max(1, int(pipeline))
         # multi-GPU sharding: this engine owns global games offset, offset+stride, ... (dist.py)
         self.index_offset, self.index_stride = int(index_offset), int(index_stride)
-        # "host": the reference's NumPy legacy stream per game (bit-exact parity mode, default);
-        # "gpu": root_sample_kernel (statistical parity only), no per-game Python sampling
-        if sampler not in ("host", "gpu"):
-            raise ValueError("sampler must be 'host' or 'gpu'")
+        # "host" (default): the reference's NumPy legacy stream per game, bit for bit, drawn for all ready games in one
+        #         native call (rootsample.py: apzh_root_sample);
+        # "numpy": the same draws through np.random.RandomState itself, one game at a time (the reference's own calls;
+        #         what "host" is tested against);
+        # "gpu":  root_sample_kernel (statistical parity only)
+        if sampler not in ("host", "numpy", "gpu"):
+            raise ValueError("sampler must be 'host', 'numpy' or 'gpu'")
         self.sampler = sampler
+        self.rng_bank = LegacyRngBank(self.G) if sampler == "host" else None
+        self._sample_threads = max(1, min(8, int(n_threads) if n_threads else 4))
         self._sample_step = 0
         self.slots = [_Slot() for _ in range(self.G)]
         self.slot_games = np.zeros(self.G, dtype=np.int64)      # games finished per slot (steady-state detection)
@@ -110,7 +116,7 @@ class SelfPlayEngine(object):
         k = self.index_offset + self.next_index * self.index_stride     # global game index
         self.next_index += 1
         slot.index = k
-        slot.rng = np.random.RandomState(self.base_seed + k)
+        self.set_slot_rng(s, self.base_seed + k)
         slot.pyrnd = _random.Random(self.base_seed + k)
         slot.codes, slot.pis, slot.movers = [], [], []
         slot.active = True
@@ -122,6 +128,21 @@ class SelfPlayEngine(object):
                 self.pool.play_move(s, mv)
             self.stats["forced_openings"] += 1
         return True
+
+    def set_slot_rng(self, s, seed_or_state):
+        """Slot s draws its root samples from np.random.RandomState(seed) -- or from a copy of the given RandomState's
+        current state (tests replay the reference's recorded streams that way)."""
+        slot = self.slots[s]
+        if self.rng_bank is not None:
+            slot.rng = None
+            if hasattr(seed_or_state, "get_state"):
+                self.rng_bank.set_state(s, seed_or_state)
+            elif 0 <= int(seed_or_state) < 2 ** 32:
+                self.rng_bank.seed(s, int(seed_or_state))
+            else:
+                self.rng_bank.set_state(s, np.random.RandomState(seed_or_state))
+        else:
+            slot.rng = seed_or_state if hasattr(seed_or_state, "get_state") else np.random.RandomState(seed_or_state)
 
     def _record(self, s, pi):
         slot = self.slots[s]
@@ -174,6 +195,19 @@ class SelfPlayEngine(object):
             for pi, move, s in zip(pis, moves, ready):
                 s = int(s)
                 self._record(s, pi.astype(np.float64))
+                ended, winner, _ = self.pool.play_move(s, int(move))
+                self.stats["moves"] += 1
+                if ended:
+                    self._finish_game(s, winner)
+                    self._start_game(s)
+            return
+        if self.sampler == "host":
+            temps = np.array([self._temp_for(len(self.slots[int(s)].movers)) for s in ready], dtype=np.float64)
+            pis, moves = sample_moves(self.rng_bank, ready, visits, temps, alpha=self.noise_alpha, eps=self.noise_eps,
+                                      with_noise=True, want_pi=True, n_threads=self._sample_threads)
+            for pi, move, s in zip(pis, moves, ready):
+                s = int(s)
+                self._record(s, pi)
                 ended, winner, _ = self.pool.play_move(s, int(move))
                 self.stats["moves"] += 1
                 if ended:

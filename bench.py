@@ -155,14 +155,18 @@ def stem_roofline(device):
     return out
 
 
-def _rank_log_dir():
+def _rank_log_dir(tag=None):
+    """gpurun_out/ (travels back from the GPU box), one sub-directory per self-spawned job: two bench runs on one host
+    must not truncate each other's rank logs, and the supervisor's silence watchdog sums the sizes of its OWN ranks' logs."""
     d = os.path.join(REPO, "gpurun_out")
+    if tag is not None:
+        d = os.path.join(d, "ranks_%s" % tag)
     try:
         os.makedirs(d, exist_ok=True)
         return d
     except OSError:
         import tempfile
-        return tempfile.gettempdir()
+        return tempfile.mkdtemp(prefix="apz_ranks_")
 
 
 def latency_probe(device):
@@ -221,12 +225,12 @@ def spawn_ranks(n, argv, deadline_s=1800.0, silence_s=420.0, early_exit_grace_s=
     if port is None:
         raise SystemExit("bench.py: no free rendezvous port in 20000..32000")
     import tempfile
-    logdir = _rank_log_dir()
+    logdir = _rank_log_dir("%d_%d" % (port, os.getpid()))
     procs, logs = [], []
     out0 = tempfile.TemporaryFile()
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), APZ_BENCH_SELF_SPAWNED="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), APZ_BENCH_SELF_SPAWNED="1")
         lf = open(os.path.join(logdir, "rank%d.log" % r), "wb")
         logs.append(lf)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=REPO,
@@ -295,8 +299,16 @@ def heartbeat(msg):
 _T_PROC = time.perf_counter()
 
 
+def local_rank_world():
+    """(rank, world) WITHIN this node: LOCAL_RANK / LOCAL_WORLD_SIZE as torchrun and spawn_ranks export them; a launcher
+    that sets only RANK / WORLD_SIZE is taken to be single-node."""
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    return rank % max(world, 1), max(world, 1)
+
+
 def pin_rank_cpus(rank, world):
-    """Give rank r of `world` its own contiguous slice of the CPUs this job may use, BEFORE anything touches the GPU
+    """Give LOCAL rank r of the `world` ranks on this node its own contiguous slice of the CPUs this job may use, BEFORE anything touches the GPU
     (threads created later -- OpenMP workers, HIP runtime, pipeline workers -- inherit it): eight ranks' tree threads
     otherwise migrate across both sockets.  Contiguous slices keep a rank inside one NUMA node on the usual layouts
     (GPUs 0-3 on socket 0, 4-7 on socket 1).  APZ_BENCH_NO_AFFINITY=1 switches it off.  -> CPUs in the slice or None."""
@@ -380,7 +392,9 @@ def main():
     if os.environ.get("APZ_BENCH_TEST_EARLY_EXIT_RANK") == os.environ.get("RANK", "0"):
         raise SystemExit(0)                                  # ... and one that leaves early with exit code 0
     ncpu = host_cpu_share()                                  # the JOB's CPU share (before this rank narrows its own mask)
-    pinned = pin_rank_cpus(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))   # before any GPU call
+    lrank, lworld = local_rank_world()
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(lworld))   # the tree pool divides its pre-touch limit by it (host_tree.cpp)
+    pinned = pin_rank_cpus(lrank, lworld)                    # before any GPU call
     heartbeat("starting (cpu slice: %s)" % pinned)
     rank, world, local = dist.init(backend="gloo" if (args.plumbing_test or args.rehearse_on_one_gpu) else None)
     if args.rehearse_on_one_gpu:
@@ -392,7 +406,7 @@ def main():
     from alphapig_amd.selfplay import SelfPlayEngine
 
     # host threads for the tree pool: this node's CPU share split evenly between its ranks
-    threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(world, 1)))
+    threads = max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), ncpu // max(lworld, 1)))
     if pinned:
         threads = max(1, min(threads, pinned))
     G = args.games
@@ -575,6 +589,8 @@ def main():
     if ranks_seen != world:
         raise SystemExit("bench.py: the all-reduce saw %d ranks, WORLD_SIZE is %d" % (ranks_seen, world))
     per_rank_rate = dist.all_gather_floats((eng.stats["leaf_evals"] - l0) / dt_local)     # a straggler is invisible under the MAX
+    rank_devices = [int(v) for v in dist.all_gather_floats(local)]                        # device ordinal of every rank
+    pg = dist.group_info()
     playouts = dist.all_reduce_sum(playouts_done() - p0)
     leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0)
     trunk_ms = trunk_cnt = fwd_ms = fwd_cnt = 0
@@ -622,7 +638,8 @@ def main():
                                "10-block/128-filter residual net, %d concurrent games per GPU" % G,
                    "games_per_gpu": G, "leaf_batch": batch, "pipeline": args.pipeline, "host_threads": threads,
                    "mean_plies_per_game": mean_plies, "mean_plies_source": plies_src, "weights": "random init seed 0"},
-        "ranks_seen": ranks_seen, "host_threads_per_rank": threads, "host_cpu_share": ncpu,
+        "ranks_seen": ranks_seen, "process_group": pg, "rank_devices": rank_devices,
+        "host_threads_per_rank": threads, "host_cpu_share": ncpu,
         "per_rank_leaf_evals_per_s": per_rank_rate, "cpus_pinned_per_rank": pinned,
         "warnings": (["host_threads_per_rank = %d < 3: the tree pool needs about three host threads per rank to keep one GPU "
                       "busy (DESIGN section 5); this run is host-bound" % threads] if threads < 3 else []),

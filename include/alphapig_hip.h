@@ -150,7 +150,7 @@ int apz_conv3x3_fwd(apz_engine *e, const void *x_dev, const void *wpk_dev, const
 int apz_conv3x3_wgrad(apz_engine *e, const void *x_dev, const void *dy_dev, void *dw_dev, int n,
                       int cin, int cout, int layout, void *stream);
 /* The same forward / data-gradient convolution for the trunk shape (128 -> 128 channels, 15x15) on the
- * fused Winograd F(4x4,3x3) kernel of the self-play path (csrc/trunk15_wino2.h):
+ * fused Winograd F(4x4,3x3) kernel of the self-play path (csrc/trunk15_wino3.h, csrc/wino_common.h):
  *   apz_wino_pack   w_dev [128][128][3][3] -> upk_dev (apz_wino_packed_size floats), U = G g G^T in fp32
  *                   on the device; transpose_flip as in apz_conv3x3_pack
  *   apz_wino_conv   y = conv(x, upk) + bias_dev (NULL: none) (ReLU if relu), x / y dense [n][128][15][15]
@@ -174,7 +174,7 @@ int apz_wino_conv_add(apz_engine *e, const void *x_dev, const void *upk_dev, con
 int apz_bn_fwd(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
                const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
                void *invstd_dev, int n, int C, int layout, int relu, float momentum, float eps, void *stream);
-/* Weight gradient of the trunk shape (128 -> 128, 15x15) through the Winograd domain (csrc/wgrad_wino.h; 3.6x fewer
+/* Weight gradient of the trunk shape (128 -> 128, 15x15) through the Winograd domain (csrc/wgrad_wino2.h; 3.6x fewer
  * MFMAs than apz_conv3x3_wgrad): x_dev / dy_dev in the padded-row layout [n][128][15][16], dw_dev [128][128][3][3]
  * overwritten. */
 int apz_wgrad_wino(apz_engine *e, const void *x_dev, const void *dy_dev, void *dw_dev, int n, void *stream);

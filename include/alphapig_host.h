@@ -141,6 +141,25 @@ int apzh_pool_info(apzh_pool *p, int64_t *out4);
 int apzh_pure_get_move(apzh_pool *p, int g, uint32_t *mt_key624, int32_t *mt_pos,
                        int32_t *acts, int64_t *visits, double *q, int cap, int32_t *n_children);
 
+/* ---- root sampling on NumPy's legacy generator (mcts_alphaZero.py:13-16, :152-155, :198-201) ------------------ */
+/* np.random.RandomState(seed) for an integer seed: fills key[624] and the position (624). */
+int apzh_mt_seed(uint32_t seed, uint32_t *key624, int32_t *pos);
+/* np.sum of a contiguous float64 vector (NumPy's pairwise summation), exposed for the tests. */
+double apzh_np_sum(const double *a, int64_t n);
+/* One move for each of g games, the way MCTSPlayer.get_action draws it.  Row i has counts[i] root children with actions
+ * acts_flat[...] (ascending, rows concatenated) and e_flat[...] = exp(x - max x), x = 1/temp * log(visits + 1e-10) -- the
+ * elementwise part of the reference's softmax, which the caller evaluates with NumPy itself (its vector exp / log are not
+ * the C library's).  Per row: probs = e / np.sum(e); pi_out[i][H*W] (may be NULL) = probs scattered at the actions;
+ * with_noise: p = (1 - eps) * probs + eps * RandomState.dirichlet(alpha * ones(k)), else p = probs;
+ * move = RandomState.choice(acts, p=p).  Every game draws from its own legacy MT19937 state keys[i][624] / pos[i] /
+ * has_gauss[i] / gauss[i] (np.random.get_state() fields), updated in place: bit for bit the stream the reference
+ * consumes.  n_threads: OpenMP threads over games. */
+int apzh_root_sample(int g, int hw, const double *e_flat, const int32_t *acts_flat, const int32_t *counts, double alpha,
+                     double eps, int with_noise, uint32_t *keys, int32_t *pos, int32_t *has_gauss, double *gauss,
+                     double *pi_out, int32_t *moves_out, int n_threads);
+/* Tree-arena pre-touch limit of one rank, GB: its share (1 / local_world) of half the available memory, at most 96. */
+double apzh_pretouch_limit_gb(double avail_gb, int local_world);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,10 +81,13 @@ def test_resnet_layers_and_heads(resnet3, n):
     np.testing.assert_allclose(net.layer_output(6, n), o_trunk, rtol=0, atol=2e-4)
 
 
-def test_resnet_full_depth_10_blocks():
-    from alphapig_amd.policy_value_net import PolicyValueNet
+@pytest.mark.parametrize("kind", ["wino3", "wino3-batched"])
+def test_resnet_full_depth_10_blocks(kind):
+    """The 10-block net (train_mxnet.py:79-91) against the float64 oracle on BOTH fp32 Winograd trunk kernels: 24 boards
+    take trunk15_wino3s_kernel by default ("wino3"); "wino3-batched" forces trunk15_wino3_kernel, the kernel the
+    self-play bench spends 97 % of its GPU time in, onto the same batch."""
     prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
-    net = PolicyValueNet(15, 15, batch_size=32, n_blocks=10, n_filter=128, model_params=prm)
+    net = _net_with_trunk_kernel(kind, prm, 10, 32)
     _, planes = random_positions(24, 15, seed=7)
     logits, probs, vlog, vals = net.forward_with_logits(planes)
     o_logits, o_probs, o_vlog, o_vals = net_ref.forward(prm, planes, "resnet", 10, np.float64)
@@ -95,6 +98,30 @@ def test_resnet_full_depth_10_blocks():
     net.set_params(prm2)
     logits2 = net.forward_with_logits(planes)[0]
     np.testing.assert_allclose(logits2, net_ref.forward(prm2, planes, "resnet", 10)[0], rtol=0, atol=LOGIT_ATOL)
+    net.close()
+
+
+def test_bench_launch_shape_10_blocks_512_boards_against_oracle():
+    """The bench's launch: 10 blocks, 512 boards in ONE forward = trunk15_wino3_kernel on a duo grid of 256 workgroups x
+    2 items (BASELINE configs[2]: two 512-leaf groups per step).  Rows at both ends of the batch, on both sides of the
+    middle (the second item of a workgroup starts at pair 128 = board 256) and 26 random rows are held to the float64
+    oracle at north_star's 1e-4 (policy_value_net_mxnet.py:70-102); the remaining rows must carry the same bits as
+    the same boards evaluated alone in a small launch (which the tests above hold to the oracle as well)."""
+    prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    net = PolicyValueNet(15, 15, batch_size=512, n_blocks=10, n_filter=128, model_params=prm)
+    _, planes = random_positions(512, 15, seed=4242)
+    logits, probs, vlog, vals = net.forward_with_logits(planes)
+    rows = sorted(set([0, 1, 255, 256, 510, 511]) | set(np.random.RandomState(9).permutation(512)[:26].tolist()))
+    o_logits, o_probs, o_vlog, o_vals = net_ref.forward(prm, planes[rows], "resnet", 10, np.float64)
+    np.testing.assert_allclose(logits[rows], o_logits, rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(vlog[rows], o_vlog[:, 0], rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(probs[rows], o_probs, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(vals[rows], o_vals[:, 0], rtol=0, atol=2e-5)
+    for lo, n in ((0, 2), (254, 4), (500, 12)):
+        small = net.forward_with_logits(planes[lo:lo + n])       # trunk15_wino3s_kernel: the same bits
+        np.testing.assert_array_equal(small[0], logits[lo:lo + n])
+        np.testing.assert_array_equal(small[2], vlog[lo:lo + n])
     net.close()
 
 
@@ -381,6 +408,29 @@ def test_small_batch_trunk_kernel_gives_the_batched_kernels_bits(n):
     np.testing.assert_allclose(a[0], o[0], rtol=0, atol=LOGIT_ATOL)
     small.close()
     batched.close()
+
+
+def test_small_batch_kernel_in_launch_reduction_over_thousands_of_mixed_launches():
+    """trunk15_wino3s_kernel's position halves meet through global slabs and one ticket word per (board, channel tile)
+    that every launch exchanges its own epoch into (csrc/trunk15_wino3s.h).  3 000 launches of changing batch sizes
+    (different subsets of the ticket words in use), residual and plain layers interleaved, on ONE engine: every forward
+    must carry the bits the batched kernel gives the same boards (policy_value_net_mxnet.py:77-83 via policy_value)."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=16, style="bench")
+    _, planes = random_positions(32, 15, seed=901)
+    batched = PolicyValueNet(15, 15, batch_size=32, n_blocks=3, n_filter=128, model_params=prm)
+    batched._ck(batched.L.apz_test_select_trunk(batched._h, 4))
+    ref_p, ref_v = batched.forward_planes(planes)
+    batched.close()
+    small = PolicyValueNet(15, 15, batch_size=32, n_blocks=3, n_filter=128, model_params=prm)
+    sizes = [1, 32, 2, 7, 31, 3, 16, 1, 24, 5]
+    rs = np.random.RandomState(4)
+    for it in range(500):                                   # 500 forwards x 6 trunk launches
+        n = sizes[it % len(sizes)]
+        lo = int(rs.randint(0, 32 - n + 1))
+        p, v = small.forward_planes(planes[lo:lo + n])
+        assert np.array_equal(p, ref_p[lo:lo + n]) and np.array_equal(v, ref_v[lo:lo + n]), (it, n, lo)
+    small.close()
 
 
 def test_prewarm_and_whole_forward_timing_hooks(resnet3):

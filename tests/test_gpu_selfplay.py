@@ -118,6 +118,40 @@ def test_full_size_properties_1024_games():
     net.close()
 
 
+def test_full_size_config2_64_games_8x8_simple_net():
+    """BASELINE configs[1] at its full size: 64 concurrent 8x8 games (4 in a row), n_playout = 200, the simple
+    6-convolution net (policy_value_net_mxnet_simple.py:68-92), for 450 rounds -- every game searches 200 playouts,
+    moves and searches on, twice -- with the size-independent properties of the 1024-game test: one leaf per active
+    game per round, priors a distribution over the legal moves, visit counts that add up, Q in [-1, 1]; and the
+    evaluations the engine consumed are the network's (a sample of recorded rows against the float64 oracle)."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("simple", 8, 8, 9, seed=1, style="bench")
+    net = PolicyValueNet(8, 8, batch_size=64, model_params=prm, net_kind="simple")
+    rec = Recorder(net)
+    eng = SelfPlayEngine(rec, 8, 8, 4, n_games=64, n_playout=200, temp=1.0, base_seed=77, pipeline=2)
+    n = eng.run_steps(150)
+    assert n == 64 * 150                                   # nobody has moved yet: one leaf per game and round
+    for g in (0, 31, 63):
+        root = eng.pool.node_children(g, 0)
+        assert root["n"] == 150 and int(root["visits"].sum()) == 149
+        assert len(root["acts"]) == 64 and abs(float(root["prior"].sum()) - 1.0) < 1e-4
+        assert np.all(np.abs(root["q"]) <= 1.0 + 1e-6)
+    n += eng.run_steps(300)                                # past two moves of every game (200 playouts each, tree re-used)
+    assert eng.stats["moves"] >= 2 * 64
+    assert 64 * 400 <= n <= 64 * 450                       # at most one evaluation per game and round (terminal leaves need none)
+    for g in (0, 63):
+        root = eng.pool.node_children(g, 0)
+        assert np.all(np.abs(root["q"]) <= 1.0 + 1e-6) and int(root["visits"].sum()) == root["n"] - 1
+    keys = list(rec.table.keys())
+    pick = [keys[i] for i in np.random.RandomState(3).permutation(len(keys))[:48]]
+    codes = np.stack([np.frombuffer(k, dtype=np.uint8) for k in pick])
+    o = net_ref.forward(prm, eng.pool.codes_to_planes(codes, 9), "simple", dtype=np.float64)
+    np.testing.assert_allclose(np.stack([rec.table[k][0] for k in pick]), o[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.array([rec.table[k][1] for k in pick]), o[3][:, 0], rtol=0, atol=2e-5)
+    eng.close()
+    net.close()
+
+
 def test_closed_loop_selfplay_train_selfplay():
     """One AlphaZero iteration on the GPU: HIP self-play -> augmentation -> (interim torch)
     train_step -> re-folded weights in the HIP evaluator -> the evaluator now agrees with the

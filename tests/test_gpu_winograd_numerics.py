@@ -1,4 +1,7 @@
-"""Numerics of the fp32 Winograd F(4x4,3x3) trunk (the default kernel, trunk15_wino3) under stress, on the GPU.
+"""Numerics of the fp32 Winograd F(4x4,3x3) trunk kernels under stress, on the GPU: the batched kernel
+(trunk15_wino3_kernel: what the self-play bench runs, forced onto these small batches through apz_test_select_trunk),
+the small-batch kernel (trunk15_wino3s_kernel: what a batch of <= 32 boards gets by default) and, opt-in, the
+3 x bf16 split kernel (trunk15_wino3b_kernel).
 
 Winograd's error grows with the magnitude of the transformed operands, so the everyday parity tests
 (tests/test_gpu_net.py: two synthetic initialisations) say little about other weight scales.  Here the full
@@ -9,11 +12,13 @@ Winograd's error grows with the magnitude of the transformed operands, so the ev
   * BatchNorm moving variances of 1e-3 (1/sqrt(var + eps) = 22: every layer amplifies) and 10,
   * dense boards (every cell occupied) and empty boards,
 
-and the direct-convolution kernel (APZ_TRUNK_KERNEL=ring: exact fp32 FMA chains, no transform) runs beside it.
+and the direct-convolution kernel (apz_test_select_trunk(APZ_TRUNK_DIRECT): exact fp32 FMA chains, no transform)
+runs beside them.
 Tolerance: north_star's 1e-4 on the logits, relative to the logit scale when that exceeds 1 (a network whose
 logits are 1e6 cannot be held to 1e-4 absolute in fp32 by any kernel), with a 3x margin: the Winograd path must
-stay below (1e-4 / 3) * max(1, max|logit|) (exploding networks: see the end of the test).  The measured table is
-written to gpurun_out/ (committed as profiles/r03_winograd_numerics.json) and quoted in DESIGN.md.
+stay below (1e-4 / 3) * max(1, max|logit|) (exploding networks: see the end of the test).  The measured table (one
+column set per kernel, each row says which kernel produced it) is written to gpurun_out/ (committed as
+profiles/r04_winograd_numerics.json) and quoted in DESIGN.md.
 """
 import json
 import os
@@ -78,35 +83,51 @@ CASES = [("base", "random"), ("base", "dense"), ("base", "empty"), ("w4_balanced
          ("w4_raw", "random"), ("w025_raw", "random"), ("var_1e-3", "random"), ("var_10", "random"), ("var_10", "dense")]
 
 
-def test_winograd_trunk_keeps_a_3x_margin_under_stress():
-    rows, worst = [], 0.0
+# kind (apz_test_select_trunk) -> the kernel that then runs these 6-board batches
+KERNEL_OF = {"wino3-batched": "trunk15_wino3_kernel", "wino3": "trunk15_wino3s_kernel", "ring": "trunk15_ring_kernel",
+             "wino3b": "trunk15_wino3b_kernel"}
+
+
+def _stress_table(kinds):
+    rows = []
     for vname, bname in CASES:
         prm = _variant(vname)
         planes = _boards(bname)
         o_logits, _, o_vlog, _ = net_ref.forward(prm, planes, "resnet", 10, np.float64)
         scale = max(1.0, float(np.abs(o_logits).max()))
         vscale = max(1.0, float(np.abs(o_vlog).max()))
-        errs = {}
-        for kind in ("wino3", "ring"):
+        row = {"weights": vname, "boards": bname, "logit_scale": scale, "value_logit_scale": vscale}
+        for kind in kinds:
             net = _net_with_trunk_kernel(kind, prm, 10, 16)
             try:
                 logits, _, vlog, _ = net.forward_with_logits(planes)
             finally:
                 net.close()
             assert np.isfinite(logits).all() and np.isfinite(vlog).all(), (vname, bname, kind)
-            errs[kind] = (float(np.abs(logits - o_logits).max()) / scale, float(np.abs(vlog - o_vlog[:, 0]).max()) / vscale)
-        rows.append({"weights": vname, "boards": bname, "logit_scale": scale, "value_logit_scale": vscale,
-                     "wino3_logit_err_rel": errs["wino3"][0], "wino3_value_err_rel": errs["wino3"][1],
-                     "ring_logit_err_rel": errs["ring"][0], "ring_value_err_rel": errs["ring"][1]})
-        worst = max(worst, errs["wino3"][0], errs["wino3"][1])
+            row[kind + "_logit_err_rel"] = float(np.abs(logits - o_logits).max()) / scale
+            row[kind + "_value_err_rel"] = float(np.abs(vlog - o_vlog[:, 0]).max()) / vscale
+        rows.append(row)
+    return rows
+
+
+def _write_table(name, kinds, rows):
     out = os.path.join(REPO, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r03_winograd_numerics.json"), "w") as f:
-        json.dump({"tolerance": TOL, "rows": rows, "worst_wino3": worst}, f, indent=1)
+    worst = {k: max(max(r[k + "_logit_err_rel"], r[k + "_value_err_rel"]) for r in rows) for k in kinds}
+    with open(os.path.join(out, name), "w") as f:
+        json.dump({"tolerance": TOL, "boards_per_batch": 6, "kernel_of_kind": {k: KERNEL_OF[k] for k in kinds},
+                   "worst": worst, "rows": rows}, f, indent=1)
     for r in rows:
-        print("%-14s %-7s scale %9.3g  wino3 %.2e / %.2e   ring %.2e / %.2e" % (
-            r["weights"], r["boards"], r["logit_scale"], r["wino3_logit_err_rel"], r["wino3_value_err_rel"],
-            r["ring_logit_err_rel"], r["ring_value_err_rel"]))
+        print("%-14s %-7s scale %9.3g  " % (r["weights"], r["boards"], r["logit_scale"]) +
+              "   ".join("%s %.2e / %.2e" % (k, r[k + "_logit_err_rel"], r[k + "_value_err_rel"]) for k in kinds))
+
+
+def test_winograd_trunk_keeps_a_3x_margin_under_stress():
+    """Both fp32 Winograd kernels -- the batched one the bench runs ("wino3-batched") and the small-batch one
+    ("wino3") -- against the float64 oracle over the 10-block net (policy_value_net_mxnet.py:70-102)."""
+    kinds = ("wino3-batched", "wino3", "ring")
+    rows = _stress_table(kinds)
+    _write_table("r04_winograd_numerics.json", kinds, rows)
     # Networks whose activations explode (raw x4 weights: logits 2e9; variances 1e-3: logits 2e26) sum terms that are
     # many orders larger than the result in the heads, so the relative error of EVERY fp32 kernel grows there, the
     # direct one's too (measured 1.4e-5 on the value logit); for those the Winograd path is held to 4x the direct
@@ -114,6 +135,11 @@ def test_winograd_trunk_keeps_a_3x_margin_under_stress():
     def bound(r, key):
         exploding = r["logit_scale"] > 1e3
         return max(TOL, 4.0 * r["ring_" + key]) if exploding else TOL
-    bad = [r for r in rows if r["wino3_logit_err_rel"] > bound(r, "logit_err_rel") or
-           r["wino3_value_err_rel"] > bound(r, "value_err_rel")]
-    assert not bad, bad
+    for kind in ("wino3-batched", "wino3"):
+        bad = [r for r in rows if r[kind + "_logit_err_rel"] > bound(r, "logit_err_rel") or
+               r[kind + "_value_err_rel"] > bound(r, "value_err_rel")]
+        assert not bad, (kind, bad)
+    # the two forms are the same arithmetic in the same order: the same bits, so the same errors
+    for r in rows:
+        assert r["wino3_logit_err_rel"] == r["wino3-batched_logit_err_rel"], r
+        assert r["wino3_value_err_rel"] == r["wino3-batched_value_err_rel"], r

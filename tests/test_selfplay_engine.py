@@ -68,7 +68,7 @@ def test_batched_equals_reference_episodes_15x15(golden_dir):
         for s in range(3):
             eng._start_game(s)
         # overwrite slot 1 with the golden seeds (slots 0 and 2 keep running beside it)
-        eng.slots[1].rng = np.random.RandomState(npseed)
+        eng.set_slot_rng(1, np.random.RandomState(npseed))
         eng.slots[1].pyrnd = random.Random(pyseed)
         eng.slots[1].codes, eng.slots[1].pis, eng.slots[1].movers = [], [], []
         eng.pool.reset(1, 0)
@@ -85,8 +85,12 @@ def test_batched_equals_reference_episodes_15x15(golden_dir):
         np.testing.assert_array_equal(e.moves, g[name + "/moves"])
         assert e.winner == int(g[name + "/winner"])
         np.testing.assert_array_equal(e.zs, g[name + "/zs"])
-        np.testing.assert_allclose(e.pis, g[name + "/pis"], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(e.pis, g[name + "/pis"])       # the native sampler restates np.sum: pi bit for bit
         np.testing.assert_array_equal(eng.pool.codes_to_planes(e.codes, 9).astype(np.uint8), g[name + "/states"])
+        # ... and the slot's generator ends where the reference's np.random ended (no new game was started on it)
+        import hashlib
+        st = eng.rng_bank.get_state(1)
+        assert hashlib.sha1(st[1].tobytes() + str(st[2]).encode()).hexdigest() == str(g[name + "/digest"])
         eng.close()
 
 
