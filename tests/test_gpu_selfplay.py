@@ -128,7 +128,7 @@ def test_full_size_config2_64_games_8x8_simple_net():
     prm = weights.init_params("simple", 8, 8, 9, seed=1, style="bench")
     net = PolicyValueNet(8, 8, batch_size=64, model_params=prm, net_kind="simple")
     rec = Recorder(net)
-    eng = SelfPlayEngine(rec, 8, 8, 4, n_games=64, n_playout=200, temp=1.0, base_seed=77, pipeline=2)
+    eng = SelfPlayEngine(rec, 8, 8, 4, n_games=64, n_playout=200, temp=1.0, base_seed=77, pipeline=2, forced_opening=False)
     n = eng.run_steps(150)
     assert n == 64 * 150                                   # nobody has moved yet: one leaf per game and round
     for g in (0, 31, 63):

@@ -1,0 +1,205 @@
+// Timing + cross-check harness for trunk15_wino3b_kernel (the 3 x bf16 split trunk): random data, HIP events, outputs
+// compared with (1) a naive double-precision kernel of the same Winograd-domain definition on the SAME fp32 weights U
+// and (2) the fp32 kernel trunk15_wino3_kernel on those weights; the error of both against (1) is printed side by side.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ialphapig_amd/csrc [-DAPZ_WINO3B_STAMPS] tools/wino3b_bench.hip -o tools/_build/wino3b_bench
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "trunk15_wino3b.h"
+
+// Y = A^T [sum_ci U (.) B^T d B] A + bias (+ resid), ReLU -- the definition, in double.  upk: wino_common.h's fp32 layout.
+__global__ void wino_ref_kernel(const float* __restrict__ in, const float* __restrict__ upk, const float* __restrict__ bias,
+                                const float* __restrict__ res, double* __restrict__ out, int n, int resid) {
+    const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (gid >= (long)n * 128 * 16) return;
+    const int tile = (int)(gid & 15), co = (int)((gid >> 4) & 127), bd = (int)(gid >> 11);
+    const int ty = tile >> 2, tx = tile & 3;
+    const double Bt[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                             {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    const double At[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    double M[6][6];
+    for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 6; k++) M[i][k] = 0.0;
+    const int cot = co >> 4, j = co & 15;
+    for (int ci = 0; ci < 128; ci++) {
+        double d[6][6], t[6][6];
+        const float* pl = in + ((size_t)bd * 128 + ci) * 240;
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) {
+                const int r = 4 * ty - 1 + i, c = 4 * tx - 1 + k;
+                d[i][k] = (r >= 0 && r < 15 && c >= 0 && c < 15) ? (double)pl[r * 16 + c] : 0.0;
+            }
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) {
+                double a = 0;
+                for (int x = 0; x < 6; x++) a += Bt[i][x] * d[x][k];
+                t[i][k] = a;
+            }
+        const int c4 = ci >> 2, q = ci & 3;
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) {
+                double v = 0;
+                for (int x = 0; x < 6; x++) v += t[i][x] * Bt[k][x];
+                const int ph = i / 3, ii = i % 3;
+                M[i][k] += (double)upk[((((size_t)cot * 2 + ph) * 32 + c4) * 64 + q * 16 + j) * 20 + 6 * ii + k] * v;
+            }
+    }
+    double* op = out + ((size_t)bd * 128 + co) * 240;
+    const float* rp = res + ((size_t)bd * 128 + co) * 240;
+    for (int a = 0; a < 4; a++)
+        for (int e = 0; e < 4; e++) {
+            const int r = 4 * ty + a, c = 4 * tx + e;
+            if (r >= 15) continue;
+            double acc = 0;
+            for (int i = 0; i < 6; i++)
+                for (int k = 0; k < 6; k++) acc += At[a][i] * M[i][k] * At[e][k];
+            acc += (double)bias[co];
+            if (resid && c < 15) acc += (double)rp[r * 16 + c];
+            op[r * 16 + c] = c < 15 ? (acc > 0 ? acc : 0.0) : 0.0;
+        }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    using T2 = apz::WinoPack;
+    using T3 = apz::Wino3;
+    using TB = apz::Wino3B;
+    const bool quick = getenv("APZ_NO_TIMING") != nullptr;
+    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3b_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TB::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TB::LDS_BYTES));
+    const int nmax = 2048;
+    const size_t act = (size_t)nmax * 128 * 240;
+    float *in, *res, *out, *out2, *upk, *bias, *zeros;
+    double* outd;
+    CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256));
+    void* upkb;
+    CK(hipMalloc(&in, act * 4)); CK(hipMalloc(&res, act * 4)); CK(hipMalloc(&out, act * 4)); CK(hipMalloc(&out2, act * 4));
+    const int nref = 1030;
+    CK(hipMalloc(&outd, (size_t)nref * 128 * 240 * 8));
+    CK(hipMalloc(&upk, T2::UPK_FLOATS * 4)); CK(hipMalloc(&bias, 128 * 4)); CK(hipMalloc(&upkb, TB::UPK_BYTES));
+    std::vector<float> h(act), hr(act);
+    srand(1);
+    // activations after a ReLU: a third zeros, the rest up to 1.4; residual of either sign
+    for (size_t i = 0; i < act; i++) h[i] = ((i & 15) == 15) ? 0.f : std::max(0.f, ((rand() % 2000) - 600) * 1e-3f);
+    for (size_t i = 0; i < act; i++) hr[i] = ((i & 15) == 15) ? 0.f : ((rand() % 2000) - 1000) * 1e-3f;
+    CK(hipMemcpy(in, h.data(), act * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(res, hr.data(), act * 4, hipMemcpyHostToDevice));
+    std::vector<float> u(T2::UPK_FLOATS, 0.f);
+    // U[pos][co][ci] random at the scale a folded 128 x 128 layer has; kept in double for the split, rounded for the fp32 pack
+    std::vector<double> ud((size_t)36 * 128 * 128);
+    for (auto& v : ud) v = ((rand() % 20000) - 10000) * 2e-6 + ((rand() % 1000) - 500) * 1e-9;
+    auto u_of = [&](int co, int ci, int pos) { return (double)(float)ud[((size_t)pos * 128 + co) * 128 + ci]; };   // both kernels get the fp32 value
+    for (int co = 0; co < 128; co++)
+        for (int ci = 0; ci < 128; ci++)
+            for (int pos = 0; pos < 36; pos++) {
+                const int i = pos / 6, k = pos % 6, half = i / 3, cot = co >> 4, jj = co & 15, qq = ci & 3, c4 = ci >> 2;
+                u[((((size_t)cot * 2 + half) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * half) * 6 + k] = (float)u_of(co, ci, pos);
+            }
+    CK(hipMemcpy(upk, u.data(), u.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t> ub;
+    apz::wino3b_pack_host(u_of, ub);
+    CK(hipMemcpy(upkb, ub.data(), TB::UPK_BYTES, hipMemcpyHostToDevice));
+    std::vector<float> hb(128);
+    for (auto& v : hb) v = ((rand() % 2000) - 1000) * 1e-4f;
+    CK(hipMemcpy(bias, hb.data(), 512, hipMemcpyHostToDevice));
+
+    // ---- cross-check against the naive double kernel at ragged sizes
+    int bad = 0;
+    const int check_sizes[7] = {1, 7, 64, 96, 512, 515, 1030};
+    std::vector<float> ha, hb3;
+    std::vector<double> hd;
+    for (int ci = 0; ci < (quick ? 3 : 7); ci++) {
+        const int n = check_sizes[ci];
+        const int grid = apz::wino3_grid(n, 256);
+        for (int resid = 0; resid < 2; resid++) {
+            const size_t cnt = (size_t)n * 128 * 240;
+            CK(hipMemset(out, 0xff, cnt * 4));
+            CK(hipMemset(out2, 0xff, cnt * 4));
+            hipLaunchKernelGGL(wino_ref_kernel, dim3((unsigned)((n * 128 * 16 + 255) / 256)), dim3(256), 0, 0, in, upk, bias, res, outd, n, resid);
+            if (resid) {
+                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+            } else {
+                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+            }
+            CK(hipGetLastError());
+            CK(hipDeviceSynchronize());
+            ha.resize(cnt); hb3.resize(cnt); hd.resize(cnt);
+            CK(hipMemcpy(ha.data(), out, cnt * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hb3.data(), out2, cnt * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hd.data(), outd, cnt * 8, hipMemcpyDeviceToHost));
+            double eb = 0, e3 = 0, scale = 0, sb = 0, s3 = 0;
+            size_t worst = 0, nonfinite = 0;
+            for (size_t i = 0; i < cnt; i++) {
+                if ((i % 240) / 16 >= 15) continue;
+                if (!std::isfinite(ha[i])) { nonfinite++; continue; }
+                const double db = std::fabs((double)ha[i] - hd[i]), d3 = std::fabs((double)hb3[i] - hd[i]);
+                if (db > eb) { eb = db; worst = i; }
+                e3 = std::max(e3, d3);
+                sb += db * db; s3 += d3 * d3;
+                scale = std::max(scale, std::fabs(hd[i]));
+            }
+            const bool ok = nonfinite == 0 && eb < 2e-5 * std::max(1.0, scale);
+            if (!ok) bad++;
+            printf("check n=%5d resid=%d grid=%d: bf16x3 max err %.3e rms %.3e | fp32 wino3 max err %.3e rms %.3e | scale %.2f nonfinite %zu %s (worst at board %zu ch %zu row %zu col %zu: %.6f vs %.6f)\n",
+                   n, resid, grid, eb, std::sqrt(sb / cnt), e3, std::sqrt(s3 / cnt), scale, nonfinite, ok ? "OK" : "MISMATCH", worst / (128 * 240),
+                   (worst / 240) % 128, (worst % 240) / 16, worst % 16, ha[worst], hd[worst]);
+        }
+    }
+    if (quick) { printf("RESULT %s\n", bad ? "MISMATCH" : "OK"); return bad ? 2 : 0; }
+
+    // ---- timing: interleaved rounds of both kernels on the same data (layer chains in place would change the data: the
+    // output goes to a scratch buffer)
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int sizes[5] = {128, 256, 512, 1024, 2048};
+    for (int si = 0; si < 5; si++) {
+        const int n = sizes[si];
+        const int grid = apz::wino3_grid(n, 256);
+        float best[2][2] = {{1e9f, 1e9f}, {1e9f, 1e9f}}, sum[2][2] = {{0, 0}, {0, 0}};
+        const int rounds = 6, iters = 20;
+        for (int r = 0; r < rounds; r++)
+            for (int kern = 0; kern < 2; kern++)
+                for (int resid = 0; resid < 2; resid++) {
+                    for (int it = -3; it < iters; it++) {
+                        if (it == 0) CK(hipEventRecord(e0, 0));
+                        if (kern == 0) {
+                            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                            else hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                        } else {
+                            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+                            else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+                        }
+                    }
+                    CK(hipEventRecord(e1, 0));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    best[kern][resid] = std::min(best[kern][resid], ms / iters);
+                    sum[kern][resid] += ms / iters;
+                }
+        printf("time n=%5d grid=%3d: bf16x3 %.1f / %.1f us (plain / resid; mean %.1f / %.1f) | fp32 wino3 %.1f / %.1f us (mean %.1f / %.1f)\n", n, grid,
+               best[0][0] * 1e3, best[0][1] * 1e3, sum[0][0] / rounds * 1e3, sum[0][1] / rounds * 1e3, best[1][0] * 1e3, best[1][1] * 1e3,
+               sum[1][0] / rounds * 1e3, sum[1][1] / rounds * 1e3);
+    }
+#ifdef APZ_WINO3B_STAMPS
+    {
+        unsigned long long st[4 * 4 * 8];
+        hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(apz::apz_wino3b_stamps), sizeof st));
+        for (int w = 0; w < 4; w++)
+            printf("stamps wg0 wave %d: prologue %llu barriers %llu chunks %llu epilogue %llu total %llu cycles\n", w, st[w * 8 + 0], st[w * 8 + 1],
+                   st[w * 8 + 2], st[w * 8 + 3], st[w * 8 + 7]);
+    }
+#endif
+    printf("RESULT %s\n", bad ? "MISMATCH" : "OK");
+    return bad ? 2 : 0;
+}
