@@ -19,6 +19,7 @@
 #include "trunk15_ring.h"
 #include "trunk15_wino3.h"
 #include "trunk15_wino3s.h"
+#include "trunk15_wino3b.h"
 #include "conv8_small.h"
 #include "wgrad_wino2.h"
 #include "sampler.h"
@@ -62,6 +63,7 @@ struct ConvLayer {
     float* wpk12 = nullptr; // 8x8 boards (conv8_kernel): [cot][c4][lane][12]
     float* upk2 = nullptr;  // trunk15_wino3_kernel: transformed weights G g G^T, [cot][row half][c4][lane][20] (wino_common.h)
     float* upk3s = nullptr; // trunk15_wino3s_kernel: the same values, [cot][wave][c4][piece][lane][4] (WinoPackSmall)
+    void* upk3b = nullptr;  // trunk15_wino3b_kernel (apz_set_trunk_arith(APZ_ARITH_BF16X3) only): U as three bf16 terms (Wino3B)
     float* bias = nullptr;
 };
 
@@ -136,6 +138,7 @@ struct apz_engine {
     unsigned* w3s_tickets = nullptr;         // ... and the pairs' ticket words (each launch exchanges its epoch in: trunk15_wino3s.h)
     unsigned w3s_epoch = 0;                  // last epoch handed out; never 0, never repeated between two memsets of the words
     bool no_small_trunk = false;             // apz_test_select_trunk(APZ_TRUNK_WINOGRAD_BATCHED): tests compare the two forms
+    int trunk_arith = APZ_ARITH_F32;         // apz_set_trunk_arith: APZ_ARITH_BF16X3 = trunk15_wino3b_kernel for batches > 32
     int trunk_kernel = APZ_TRUNK_WINOGRAD;   // or APZ_TRUNK_DIRECT (trunk15_ring_kernel): apz_test_select_trunk, tests only
     // profiling
     bool profiling = false;
@@ -403,7 +406,36 @@ int launch_wino3_t(apz_engine* e, int attr_slot, const float* in, const float* u
     return APZ_OK;
 }
 
+// The 3 x bf16 split kernel (opt-in): same layouts, same grids, 512 threads
+template <bool RESID>
+int launch_wino3b_t(apz_engine* e, int attr_slot, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Wino3B;
+    bool& configured = e->lds_attr_set[attr_slot];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3b_kernel<RESID, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T::LDS_BYTES));
+        configured = true;
+    }
+    if (!e->zeros256) {
+        HIP_TRY(hipMalloc((void**)&e->zeros256, 256 * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(e->zeros256, 0, 256 * sizeof(float), e->stream));
+    }
+    for (int b0 = 0; b0 < n; b0 += WINO3_MAX_BOARDS) {
+        const int nb = std::min(n - b0, WINO3_MAX_BOARDS);
+        const size_t off = (size_t)b0 * T::C * T::GPLANE;
+        const int grid = apz::wino3_grid(nb, e->num_cu);
+        hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<RESID, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in + off,
+                           (const void*)L.upk3b, L.bias, RESID ? resid + off : nullptr, out + off, nb, (const float*)e->zeros256);
+    }
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    if (e->trunk_arith == APZ_ARITH_BF16X3 && L.upk3b && (n > apz::Wino3S::MAX_BOARDS || e->no_small_trunk)) {
+        if (resid) return launch_wino3b_t<true>(e, 26, L, in, resid, out, n);
+        return launch_wino3b_t<false>(e, 27, L, in, resid, out, n);
+    }
     if (resid) return launch_wino3_t<true, true>(e, 6, in, L.upk2, L.bias, resid, out, n, L.upk3s);
     return launch_wino3_t<false, true>(e, 7, in, L.upk2, L.bias, nullptr, out, n, L.upk3s);
 }
@@ -638,6 +670,7 @@ void apz_destroy(apz_engine* e) {
         if (l.wpk) hipFree(l.wpk);
         if (l.upk2) hipFree(l.upk2);
         if (l.upk3s) hipFree(l.upk3s);
+        if (l.upk3b) hipFree(l.upk3b);
         if (l.wpk12) hipFree(l.wpk12);
         if (l.bias) hipFree(l.bias);
     }
@@ -836,6 +869,22 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
             if (rc) return rc;
             rc = upload(&L.upk3s, up3s);
             if (rc) return rc;
+            if (e->trunk_arith == APZ_ARITH_BF16X3) {
+                // the same U as three bf16 terms (round to nearest even, the remainder taken in double): trunk15_wino3b.h
+                std::vector<uint16_t> ub;
+                apz::wino3b_pack_host(
+                    [&](int co, int ci, int pos) {
+                        double g[3][3], t[3];
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) g[a][b] = (double)w[((size_t)co * 128 + ci) * 9 + a * 3 + b] * scale[co];
+                        const int i = pos / 6, k = pos % 6;
+                        for (int b = 0; b < 3; b++) t[b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+                        return t[0] * G[k][0] + t[1] * G[k][1] + t[2] * G[k][2];
+                    },
+                    ub);
+                if (!L.upk3b) HIP_TRY(hipMalloc(&L.upk3b, apz::Wino3B::UPK_BYTES));
+                HIP_TRY(hipMemcpy(L.upk3b, ub.data(), apz::Wino3B::UPK_BYTES, hipMemcpyHostToDevice));
+            }
         }
     }
     // heads: two 1x1 conv_act (fix_gamma default) folded into one [6][C] matrix
@@ -1175,6 +1224,11 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
                                L.cin, n4, ncot, (int)x4);
             if (x4)
                 hipLaunchKernelGGL(apz::pack_wino_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale, L.upk2, L.upk3s);
+            if (x4 && e->trunk_arith == APZ_ARITH_BF16X3) {
+                if (!L.upk3b) HIP_TRY(hipMalloc(&L.upk3b, apz::Wino3B::UPK_BYTES));
+                hipLaunchKernelGGL(apz::pack_wino3b_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale,
+                                   (unsigned short*)L.upk3b);
+            }
             if (e->small8 && L.wpk12)
                 hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale,
                                    L.wpk12, L.cin, n4, ncot, 1);
@@ -1823,6 +1877,17 @@ int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
     for (size_t pc = 0; pc < (size_t)e->last_n * C; pc++)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) host_out[(pc * H + y) * W + x] = tmp[pc * e->act_ps + y * e->act_rs + x];
+    return APZ_OK;
+}
+
+int apz_set_trunk_arith(apz_engine* e, int arith) {
+    if (!e || (arith != APZ_ARITH_F32 && arith != APZ_ARITH_BF16X3)) return fail(APZ_E_ARG, "bad trunk arithmetic");
+    EngineLock guard(e->submit_lock);
+    if (arith == APZ_ARITH_BF16X3 && !e->ring)
+        return fail(APZ_E_UNSUPPORTED, "the bf16 x 3 trunk kernel exists for the 15x15 / 128-filter residual net only");
+    if (e->loaded && arith != e->trunk_arith)
+        return fail(APZ_E_STATE, "apz_set_trunk_arith must be called before the weights are loaded");
+    e->trunk_arith = arith;
     return APZ_OK;
 }
 

@@ -4,6 +4,7 @@
 // modules after every step).  The host path costs a device -> host copy of every tensor, 16 ms of folding and
 // Winograd packing on one core and the upload; these kernels take a few tens of microseconds.  gfx950.
 #pragma once
+#include "trunk15_wino3b.h"
 #include "wino_common.h"
 #include <hip/hip_runtime.h>
 
@@ -68,6 +69,38 @@ __global__ void pack_wino_folded_kernel(const float* __restrict__ w, const doubl
             const int pass = i / 3;
             up2[((((size_t)cot * 2 + pass) * 32 + c4) * 64 + (qq * 16 + jj)) * 20 + (i - 3 * pass) * 6 + k] = (float)u;
             if (up3s) up3s[WinoPackSmall::index(co, ci, 6 * i + k)] = (float)u;
+        }
+}
+
+// The same U as three bf16 terms for trunk15_wino3b.h (Wino3B::upk_offset): round to nearest even, remainders in double.
+__global__ void pack_wino3b_folded_kernel(const float* __restrict__ w, const double* __restrict__ scale, unsigned short* __restrict__ up) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 128 * 128) return;
+    const int co = idx >> 7, ci = idx & 127;
+    const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double g[3][3], t[6][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) g[a][b] = (double)w[((size_t)co * 128 + ci) * 9 + a * 3 + b] * scale[co];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double rem = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
+#pragma unroll
+            for (int term = 0; term < 3; term++) {
+                unsigned u = __builtin_bit_cast(unsigned, (float)rem);
+                if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);
+                u &= 0xffff0000u;
+                up[Wino3B::upk_offset(co, ci, 6 * i + k, term) / 2] = (unsigned short)(u >> 16);
+                rem -= (double)__builtin_bit_cast(float, u);
+            }
         }
 }
 

@@ -42,6 +42,7 @@ def init(backend=None, device_index=None, force=False):
 
 
 _ACTIVE = False        # a process group was requested: only then do the helpers below touch torch
+last_gather_total = 0  # all_gather_tuples: number of tuples all ranks contributed to the last exchange
 
 
 def shard_indices(total_games, rank, world):
@@ -208,6 +209,8 @@ def all_gather_tuples(codes, pis, zs, consumer=None):
     mine = torch.tensor([T], dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, mine)
     counts = counts.cpu().numpy()
+    global last_gather_total
+    last_gather_total = int(counts.sum())            # tuples in the exchange, on every rank (also on non-consumers)
     tmax = int(counts.max())
     if tmax == 0:
         return codes[:0], pis[:0], zs[:0]

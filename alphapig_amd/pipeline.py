@@ -29,10 +29,31 @@ one process per GPU, `distributed=True` (default: on when alphapig_amd.dist hold
                  (device to device) and goes on playing with them.
 The reference has no multi-process collector (train_mxnet.py:182-191 is commented out); the loop is its `run`
 (train_mxnet.py:265-300) with collect -> all-gather -> update -> broadcast.
+
+Two schedules (`async_update` in the configuration; default True):
+  lock step    (False) the loop above, literally: every rank waits while rank 0 trains / evaluates (round 3; measured on
+               one MI355X: the update is 55 % of the wall clock and self-play falls to 39 % of its rate; on N ranks every
+               GPU idles through every update).
+  asynchronous (True)  nobody waits for the trainer.  Self-play runs in ROUNDS of `round_seconds` wall clock (or
+               `round_steps` engine steps); at the end of a round every rank hands over the games it finished since the
+               last one (any number, also none) in one all-gather and receives a 9-float header from rank 0; weights
+               travel only in rounds in which rank 0 has a NEW version.  On rank 0 the trainer lives in its own thread
+               with its own HIP stream, its own evaluator handle (KL monitor, arena) and its own HipTrainer: it takes
+               the gathered game batches from a queue, puts them into the replay buffer, runs `policy_update` -- one per
+               game batch like the reference, never more; batches that arrive while an update runs are merged into the
+               next one and counted as `updates_skipped` -- saves / evaluates on the reference's schedule and publishes a
+               snapshot of the weights, which the next round broadcasts.  Staleness bound: a rank plays with weights that
+               are at most (one round + one policy_update + one broadcast) older than the trainer's; the switch can fall
+               inside a game, as in lock step.  `max_update_share` < 1 makes the trainer pause after an update so that it
+               is busy at most that share of the time (on ONE GPU self-play and training share the device: the
+               reference's one-update-per-game rule costs 0.36 - 0.55 of it; see profiles/r04_train_loop_15x15.log).
 """
 import logging
 import os
+import queue
 import random
+import threading
+import time
 
 import numpy as np
 
@@ -89,11 +110,21 @@ class ReplayBuffer(object):
 
 
 class TrainPipeline(object):
-    def __init__(self, conf, init_model=None, policy_value_net=None, device=0, seed=0, distributed=None, trainer=None):
+    def __init__(self, conf, init_model=None, policy_value_net=None, device=0, seed=0, distributed=None, trainer=None,
+                 eval_net=None):
         """policy_value_net: an evaluator to use instead of building the HIP PolicyValueNet (needs evaluate_codes, params /
         set_params; policy_value for the KL monitor on rank 0).  trainer: an object with HipTrainer's interface
         (train_step, get_params; optionally sync_evaluator) to use instead of creating a HipTrainer -- the CPU tests pass
-        stand-ins for both.  distributed: None = on iff alphapig_amd.dist holds a process group."""
+        stand-ins for both.  eval_net (asynchronous schedule, rank 0): the trainer thread's own evaluator for the KL
+        monitor, checkpoints and the arena; default: a second HIP PolicyValueNet, or `policy_value_net` itself when one
+        was passed in.  distributed: None = on iff alphapig_amd.dist holds a process group."""
+        self.async_update = bool(conf.get("async_update", True))
+        self.round_seconds = float(conf.get("round_seconds", 0.5))
+        self.round_steps = conf.get("round_steps")
+        self.max_update_share = float(conf.get("max_update_share", 1.0))
+        self._custom_net = policy_value_net is not None
+        self._eval_net = eval_net
+        self._device = device
         self.distributed = dist.is_active() if distributed is None else bool(distributed)
         self.rank, self.world = dist.rank_world() if self.distributed else (0, 1)
         self._trainer_override = trainer
@@ -135,6 +166,17 @@ class TrainPipeline(object):
         self._rng = random.Random(seed)
         self.episode_len = 0
         self.history = []
+        # asynchronous schedule
+        self.weights_version = 0
+        self.weight_broadcasts = 0
+        self.update_intervals = []              # rank 0: (start, end) wall clock of every policy_update (time.time())
+        self.round_log = []                     # every rank: (time.time(), leaf evaluations so far) at the end of each round
+        self.updates_done = self.updates_skipped = 0
+        self._train_q = None
+        self._fresh = None
+        self._lock = threading.Lock()
+        self._trainer_error = None
+        self._last = (0.0, 0.0, 0.0)
 
     # ---- data collection -----------------------------------------------------------------
     def collect_selfplay_data_ai(self, n_games=1):
@@ -153,7 +195,7 @@ class TrainPipeline(object):
             pis = np.concatenate([e.pis for e in eps]).astype(np.float32)
             zs = np.concatenate([e.zs for e in eps]).astype(np.float32)
             codes, pis, zs = dist.all_gather_tuples(codes, pis, zs, consumer=None if self.keep_replica_buffers else 0)   # THE exchange of the round (RCCL all-gather)
-            self.last_gathered = len(zs)
+            self.last_gathered = dist.last_gather_total
             if self.rank != 0 and not self.keep_replica_buffers:
                 return
             states = self.engine.pool.codes_to_planes(codes, 9)
@@ -182,13 +224,14 @@ class TrainPipeline(object):
                                       device_index=net._device, seed=self._seed, dropout_step0=self._train_steps)
         return net._trainer
 
-    def policy_update(self):
-        """train_mxnet.py:194-240 (rank 0 of a multi-rank run; see `_exchange_update`)."""
+    def policy_update(self, trainer=None, kl_net=None):
+        """train_mxnet.py:194-240 (rank 0 of a multi-rank run; see `_exchange_update` / `_trainer_main`).  Lock step: the
+        self-play evaluator itself supplies the old / new predictions of the KL monitor (re-folded per epoch);
+        asynchronous: the trainer thread's own evaluator `kl_net` does, and the self-play evaluator is left alone."""
         mini = self.data_buffer.sample(self._rng, self.batch_size)
-        net = self.policy_value_net
-        trainer = self._trainer()
+        net = self.policy_value_net if kl_net is None else kl_net
+        trainer = self._trainer() if trainer is None else trainer
         t_before = getattr(trainer, "t", 0)
-        # the self-play evaluator itself supplies the old / new predictions of the KL monitor (re-folded per epoch)
         loss, entropy, kl, self.lr_multiplier = policy_update(trainer, mini, self.learn_rate, self.lr_multiplier,
                                                               self.epochs, self.kl_targ, evaluator=_KeepTrainer(net))
         self._train_steps += max(0, getattr(trainer, "t", 0) - t_before)
@@ -234,19 +277,21 @@ class TrainPipeline(object):
             self._template = {k: np.zeros(v.shape, np.float32) for k, v in self.policy_value_net.params().items()}
         return self._template
 
-    def policy_evaluate(self, n_games=None):
+    def policy_evaluate(self, n_games=None, net=None):
         """train_mxnet.py:242-263: win ratio of the current net against pure MCTS."""
-        res = Arena(self.policy_value_net, self.board_width, self.board_height, self.n_in_row,
+        res = Arena(net or self.policy_value_net, self.board_width, self.board_height, self.n_in_row,
                     n_playout=self.n_playout, c_puct=self.c_puct, pure_mcts_playout_num=self.pure_mcts_playout_num,
                     base_seed=len(self.history)).play(n_games or self.eval_games)
         return win_ratio(res)
 
     def run(self):
         """train_mxnet.py:265-300; with several ranks every rank runs this loop (module docstring)."""
+        if self.async_update:
+            return self._run_async()
         lead = self.rank == 0
         for i in range(self.game_batch_num):
             if i < self.sgf_batches and self._training_data:
-                if lead:                                    # game records are rank 0's: the other ranks keep playing
+                if lead:                                    # game records are rank 0's (lock step: the other ranks wait in the next collective)
                     self.collect_selfplay_data(i)
             else:
                 self.collect_selfplay_data_ai(self.play_batch_size)
@@ -268,9 +313,202 @@ class TrainPipeline(object):
             _logger.info("batch %s", rec)
         return self.history
 
+    # ---- the asynchronous schedule (module docstring) ---------------------------------------------
+    def _play_round(self):
+        if self.round_steps:
+            self.engine.run_steps(int(self.round_steps))
+            return
+        t_end = time.perf_counter() + self.round_seconds
+        while True:
+            self.engine.run_steps(8)
+            if time.perf_counter() >= t_end:
+                return
+
+    def _schedule_after_batch(self, i, rec, net):
+        """The reference's per-batch schedule behind the update (train_mxnet.py:283-298): checkpoint every 50 batches,
+        arena every check_freq.  i = 0-based game-batch index."""
+        if (i + 1) % 50 == 0:
+            os.makedirs(self.model_dir, exist_ok=True)
+            net.save_model(os.path.join(self.model_dir, "current_policy.model"))
+        if (i + 1) % self.check_freq == 0:
+            rec["win_ratio"] = wr = self.policy_evaluate(net=net)
+            if wr > self.best_win_ratio:
+                self.best_win_ratio = wr
+                os.makedirs(self.model_dir, exist_ok=True)
+                net.save_model(os.path.join(self.model_dir, "best_policy_%s.model" % i))
+                if self.best_win_ratio >= 0.98 and self.pure_mcts_playout_num < 8000:
+                    self.pure_mcts_playout_num += 1000
+                    self.best_win_ratio = 0.0
+
+    def _trainer_main(self):
+        """Rank 0's trainer thread: replay buffer, policy_update, checkpoints, arena -- never on the self-play path."""
+        try:
+            import contextlib
+            ctx = contextlib.nullcontext()
+            net = self.policy_value_net
+            kl_net = self._eval_net
+            trainer = self._trainer_override
+            if trainer is None:
+                import torch
+                from .train import HipTrainer
+                stream = torch.cuda.Stream(device=net._device)
+                ctx = torch.cuda.stream(stream)      # this thread's kernels: a stream of their own, beside the self-play stream
+                if kl_net is None:
+                    kl_net = self._eval_net = PolicyValueNet(
+                        self.board_width, self.board_height, self.batch_size, n_blocks=net._n_blocks,
+                        n_filter=net._n_filter, model_params=net.params(), net_kind=net.net_kind, device=net._device)
+                    self._own_eval_net = True
+            elif kl_net is None:
+                kl_net = self._eval_net = net
+            with ctx:
+                if trainer is None:
+                    trainer = HipTrainer(net.params(), net.net_kind, net._n_blocks, batch_size=self.batch_size,
+                                         device_index=net._device, seed=self._seed)
+                self._async_trainer = trainer
+                games_recv = batches_done = 0
+                busy_until = 0.0
+                stop = False
+                while not stop:
+                    items = [self._train_q.get()]
+                    while True:
+                        try:
+                            items.append(self._train_q.get_nowait())
+                        except queue.Empty:
+                            break
+                    for it in items:
+                        if it is None:
+                            stop = True
+                            continue
+                        codes, pis, zs, n_games = it
+                        states = self.engine.pool.codes_to_planes(codes, 9)
+                        self.data_buffer.extend(get_equi_data(list(zip(states, pis, zs)), self.board_height, self.board_width))
+                        games_recv += n_games
+                    due = games_recv // self.play_batch_size - batches_done
+                    if due <= 0:
+                        continue
+                    first = batches_done
+                    batches_done += due
+                    rec = {"batch": batches_done, "buffer": len(self.data_buffer)}
+                    if len(self.data_buffer) > self.batch_size:
+                        now = time.time()
+                        if now < busy_until and not stop:
+                            time.sleep(busy_until - now)            # max_update_share: leave the device to self-play
+                        t0 = time.time()
+                        loss, entropy, kl = self.policy_update(trainer, kl_net)
+                        snap = self._snapshot(trainer)
+                        t1 = time.time()
+                        self.update_intervals.append((t0, t1))
+                        if self.max_update_share < 1.0:
+                            busy_until = t1 + (t1 - t0) * (1.0 / max(self.max_update_share, 1e-3) - 1.0)
+                        with self._lock:
+                            self.updates_done += 1
+                            self.updates_skipped += due - 1
+                            self._last = (loss, entropy, kl)
+                            self._fresh = (self.updates_done, snap)
+                        rec.update(loss=loss, entropy=entropy, kl=kl)
+                    for i in range(first, batches_done):
+                        self._schedule_after_batch(i, rec, kl_net)
+                    with self._lock:
+                        self.trainer_history.append(rec)
+        except BaseException as e:          # surfaces in the main thread at the next round
+            self._trainer_error = e
+
+    def _snapshot(self, trainer):
+        """A private copy of the trainer's weights for the main thread to broadcast / load while the trainer goes on."""
+        if hasattr(trainer, "p") and hasattr(trainer, "torch"):
+            snap = {k: v.clone() for k, v in trainer.p.items()}
+            trainer.torch.cuda.current_stream(trainer.device).synchronize()
+            return snap
+        return trainer.get_params()
+
+    def _install_weights(self, version, snap):
+        """One round's weight exchange: rank 0 sends snapshot `snap`, everybody (rank 0 included) loads it into the
+        self-play evaluator."""
+        net = self.policy_value_net
+        src = snap if self.rank == 0 else self._param_template()
+        got = dist.broadcast_params({k: src[k] for k in sorted(src)}, src=0) if self.distributed else dict(src)
+        first = next(iter(got.values()))
+        if getattr(first, "is_cuda", False) and hasattr(net, "load_device_params"):
+            self._held = got                 # the evaluator packs from these tensors asynchronously: keep them alive
+            net.load_device_params(got)
+        else:
+            net.set_params({k: (v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)) for k, v in got.items()},
+                           **({"_keep_trainer": True} if self._custom_net else {}))
+        self.weights_version = version
+        self.weight_broadcasts += 1
+
+    def _run_async(self):
+        lead = self.rank == 0
+        target_games = self.game_batch_num * self.play_batch_size * self.world
+        self.trainer_history = []
+        self._games_collected = 0
+        if lead:
+            self._train_q = queue.Queue()
+            self._trainer_thread = threading.Thread(target=self._trainer_main, name="apz-trainer", daemon=True)
+            self._trainer_thread.start()
+        rnd = 0
+        stop = False
+        while not stop:
+            rnd += 1
+            self._play_round()
+            eps = self.engine.finished[:]
+            del self.engine.finished[:len(eps)]
+            self._taken += len(eps)
+            if eps:
+                self.episode_len = int(np.mean([len(e.moves) for e in eps]))
+                codes = np.concatenate([e.codes for e in eps])
+                pis = np.concatenate([e.pis for e in eps]).astype(np.float32)
+                zs = np.concatenate([e.zs for e in eps]).astype(np.float32)
+            else:
+                codes = np.zeros((0, self.engine.pool.code_stride), np.uint8)
+                pis = np.zeros((0, self.board_width * self.board_height), np.float32)
+                zs = np.zeros(0, np.float32)
+            n_games = len(eps)
+            if self.distributed:
+                n_games = int(round(dist.all_reduce_sum(len(eps))))
+                codes, pis, zs = dist.all_gather_tuples(codes, pis, zs, consumer=0)      # THE exchange of the round
+            self.last_gathered = n_games
+            head = [0.0] * 9
+            fresh = None
+            if lead:
+                if self._trainer_error is not None:
+                    raise RuntimeError("the trainer thread died") from self._trainer_error
+                self._games_collected += n_games
+                if len(zs):
+                    self._train_q.put((codes, pis, zs, n_games))
+                done = self._games_collected >= target_games
+                if done:                                # drain: the only time anybody waits for the trainer
+                    self._train_q.put(None)
+                    self._trainer_thread.join()
+                    if self._trainer_error is not None:
+                        raise RuntimeError("the trainer thread died") from self._trainer_error
+                with self._lock:
+                    fresh, self._fresh = self._fresh, None
+                    loss, entropy, kl = self._last
+                    head = [1.0 if done else 0.0, float(fresh[0]) if fresh else float(self.weights_version),
+                            float(self.updates_done), loss, entropy, kl, self.lr_multiplier, float(self._games_collected),
+                            float(self.updates_skipped)]
+            if self.distributed:
+                head = dist.broadcast_floats(head, src=0)
+            version = int(head[1])
+            rec = {"round": rnd, "games": n_games, "games_collected": int(head[7]), "version": version,
+                   "updates": int(head[2]), "updates_skipped": int(head[8]), "leaf_evals": int(self.engine.stats["leaf_evals"])}
+            if version > self.weights_version:
+                self._install_weights(version, fresh[1] if fresh else None)
+                rec.update(loss=head[3], entropy=head[4], kl=head[5], lr_multiplier=head[6])
+            self.round_log.append((time.time(), int(self.engine.stats["leaf_evals"])))
+            self.history.append(rec)
+            stop = head[0] == 1.0
+        return self.history
+
     def close(self):
         self.engine.close()
         self.policy_value_net.close()
+        if getattr(self, "_own_eval_net", False):
+            self._eval_net.close()
+        tr = getattr(self, "_async_trainer", None)
+        if tr is not None and tr is not self._trainer_override and hasattr(tr, "close"):
+            tr.close()
 
 
 class _KeepTrainer(object):

@@ -27,7 +27,10 @@ class EvaluatorError(RuntimeError):
 
 class PolicyValueNet(object):
     def __init__(self, board_width, board_height, batch_size=512, n_blocks=8, n_filter=128,
-                 model_params=None, net_kind="resnet", c_in=9, device=0, seed=0, init_style="reference"):
+                 model_params=None, net_kind="resnet", c_in=9, device=0, seed=0, init_style="reference", trunk_arith="f32"):
+        """trunk_arith: "f32" (default: exact fp32 products, the bits the parity tests rest on) or "bf16x3" -- batches of
+        more than 32 boards of the 15x15 / 128-filter residual net then run csrc/trunk15_wino3b.h: every fp32 operand as
+        three bf16 terms on the bf16 matrix pipe, fp32 accumulation; fp32-accurate, different low-order bits."""
         self.L = _native.hip()
         self.board_width, self.board_height = int(board_width), int(board_height)
         self.batchsize = int(batch_size)
@@ -44,6 +47,11 @@ class PolicyValueNet(object):
         self._h = self.L.apz_create(C.byref(cfg))
         if not self._h:
             raise EvaluatorError("apz_create failed: %s" % self.L.apz_last_error().decode())
+        if trunk_arith not in ("f32", "bf16x3"):
+            raise ValueError("trunk_arith must be 'f32' or 'bf16x3'")
+        self.trunk_arith = trunk_arith
+        if trunk_arith == "bf16x3":
+            self._ck(self.L.apz_set_trunk_arith(self._h, 1))         # before the weights are loaded: they are packed for it
         if model_params is None:
             model_params = weights.init_params(net_kind, self.board_height, self.board_width, self.channelnum,
                                                self._n_blocks, self._n_filter, seed=seed, style=init_style)

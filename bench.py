@@ -49,6 +49,7 @@ N_FILTER = 128
 GAMES_PER_GPU = 1024
 CALIB = os.path.join(REPO, "profiles", "calibration_r03.json")
 FP32_MATRIX_PEAK_TF = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA peak
+BF16_MATRIX_PEAK_TF = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -153,6 +154,60 @@ def stem_roofline(device):
                                  "tflops": 2.0 * n * c_in * 9 * N_FILTER * H * W / ms / 1e9}
         net.close()
     return out
+
+
+def bf16x3_line(device, threads, G, pipeline, mean_plies, steps=120, warmup=30):
+    """The SAME workload (BASELINE configs[2]) with the trunk on the bf16 matrix pipe at fp32 accuracy: PolicyValueNet(...,
+    trunk_arith="bf16x3") -> csrc/trunk15_wino3b.h (every fp32 operand as three bf16 terms, six bf16 products per fp32
+    product, fp32 accumulation).  An EXTRA object: the line's `value` / `dtype` stay the exact-fp32 kernel's.  Own engine,
+    own timed region (declared: `warmup` untimed steps + the 0.6 s pre-warm, then `steps` timed ones), trunk launches timed
+    by HIP events on the engine stream."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    from alphapig_amd.selfplay import SelfPlayEngine
+    prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
+    batch = (G + pipeline - 1) // pipeline
+    net = PolicyValueNet(W, H, batch_size=batch, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, device=device,
+                         trunk_arith="bf16x3")
+    eng = SelfPlayEngine(net, W, H, N_IN_ROW, n_games=G, n_playout=N_PLAYOUT, c_puct=5, temp=1.0, base_seed=20260000,
+                         n_threads=threads, pipeline=pipeline)
+    eng.run_steps(0)
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < 0.6:
+        net.prewarm(batch, 8)
+        net.sync()
+    eng.run_steps(warmup)
+    net.prewarm(batch, 4)
+    p0 = eng.stats["leaf_evals"] + eng.terminal_playouts()
+    l0 = eng.stats["leaf_evals"]
+    net.set_profiling(max(1, (steps * pipeline) // 40))
+    t0 = time.perf_counter()
+    eng.run_steps(steps)
+    net.sync()
+    dt = time.perf_counter() - t0
+    trunk_ms, trunk_cnt = net.kernel_time_ms("trunk")
+    fwd_ms, fwd_cnt = net.kernel_time_ms("forward")
+    net.set_profiling(False)
+    playouts = eng.stats["leaf_evals"] + eng.terminal_playouts() - p0
+    leafs = eng.stats["leaf_evals"] - l0
+    eng.close()
+    net.close()
+    us = 1e3 * trunk_ms / max(trunk_cnt, 1)
+    # executed bf16 MFMA flops per launch: 36 positions x 4 groups of 32 output channels x 16 chunks x 3 v_mfma_f32_32x32x16_bf16
+    # (32 768 flop) per board PAIR
+    executed = (batch / 2.0) * 36 * 4 * 16 * 3 * 32768.0
+    tf = executed / (us * 1e-6) / 1e12 if trunk_cnt else None
+    return {"dtype": "f32-accurate via 3 x bf16 split, fp32 accumulate (opt-in: PolicyValueNet(trunk_arith='bf16x3'))",
+            "value": playouts / N_PLAYOUT / mean_plies / dt, "unit": "games/s", "leaf_evals_per_s": leafs / dt,
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+            "gpu_busy_frac": (fwd_ms * 1e-3 / dt) if fwd_cnt else None,
+            "roofline": {"kernel": "trunk15_wino3b_kernel<RESID>", "bound": "mfma", "achieved": tf, "peak": BF16_MATRIX_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": (tf / BF16_MATRIX_PEAK_TF) if tf else None, "us_per_launch": us,
+                         "launches": trunk_cnt, "boards_per_launch": batch, "flops_per_launch": executed,
+                         "achieved_basis": "bf16 MFMA flops the kernel executes (six bf16 products per fp32 product) / average launch "
+                                           "duration (HIP events); the same launch does the work of the fp32 kernel's 9.66 GFLOP",
+                         "fp32_equivalent_tflops": (batch * 9216 * 2048.0 / (us * 1e-6) / 1e12) if trunk_cnt else None},
+            "numerics": "tests/test_gpu_winograd_numerics.py::test_bf16x3_split_trunk_is_fp32_accurate_under_stress, "
+                        "profiles/r04_winograd_numerics_bf16x3.json"}
 
 
 def _rank_log_dir(tag=None):
@@ -687,6 +742,7 @@ def main():
     if not args.no_extras and world == 1 and not args.plumbing_test:
         line["roofline_stem"] = stem_roofline(local)
         line["latency"] = latency_probe(local)
+        line["trunk_bf16x3"] = bf16x3_line(local, threads, G, args.pipeline, mean_plies)
         line["cpu_baseline"] = cpu_baseline(mean_plies, cores=max(1, min(16, ncpu)))
     print(json.dumps(line))
 

@@ -253,6 +253,14 @@ int apz_set_profiling(apz_engine *e, int on);
 /* TEST HOOK.  The 15x15 / 128-filter residual net has two trunk convolution kernels: the fused F(4x4,3x3) Winograd kernel
  * (default, csrc/trunk15_wino3.h) and the direct convolution (csrc/trunk15_ring.h) that the tests use as the in-tree
  * cross-check of the former (exact fp32 FMA chains, no transform).  Takes effect from the next forward. */
+/* Arithmetic of the 128 -> 128 trunk convolutions of the 15x15 residual net (policy_value_net_mxnet.py:77-83), to be
+ * chosen BEFORE apz_load_weights.  APZ_ARITH_F32 (default): exact fp32 products on the fp32 matrix pipe -- the bits the
+ * parity tests rest on.  APZ_ARITH_BF16X3: batches of more than 32 boards run csrc/trunk15_wino3b.h -- every fp32 operand
+ * as three bf16 terms, six bf16 products per fp32 product, fp32 accumulation: fp32-accurate (tests/
+ * test_gpu_winograd_numerics.py), different low-order bits. */
+#define APZ_ARITH_F32 0
+#define APZ_ARITH_BF16X3 1
+int apz_set_trunk_arith(apz_engine *e, int arith);
 #define APZ_TRUNK_DIRECT 0
 #define APZ_TRUNK_WINOGRAD 3            /* default: batches of <= 32 boards take the small-batch form (csrc/trunk15_wino3s.h) */
 #define APZ_TRUNK_WINOGRAD_BATCHED 4    /* ... the batched form for every batch size (the tests hold the two forms to bit equality) */

@@ -40,6 +40,9 @@ class TiltNet(object):
         self._p = {k: np.asarray(prm[k], np.float32).copy() for k in ("w", "b")}
         self.sets += 1
 
+    def save_model(self, path):
+        np.savez(path, **self._p)
+
     def close(self):
         pass
 
@@ -73,7 +76,7 @@ def main_real(out_dir):
     rank, world, _ = dist.init(backend="gloo")
     conf = {"board_width": 15, "board_height": 15, "n_in_row": 5, "learn_rate": 1e-3, "lr_multiplier": 1.0, "temp": 1.0,
             "n_playout": 6, "c_puct": 5, "buffer_size": 100000, "batch_size": 32, "epochs": 2, "kl_targ": 0.02,
-            "check_freq": 1000, "game_batch_num": 3, "play_batch_size": 2, "pure_mcts_playout_num": 10,
+            "check_freq": 1000, "game_batch_num": 3, "play_batch_size": 2, "pure_mcts_playout_num": 10, "async_update": False,
             "concurrent_games": 16, "n_blocks": 1, "n_filter": 128, "model_dir": os.path.join(out_dir, "models%d" % rank)}
     pipe = TrainPipeline(conf, device=0, seed=5)
     assert pipe.distributed and (pipe.rank, pipe.world) == (rank, world)
@@ -91,14 +94,54 @@ def main_real(out_dir):
     dist.shutdown()
 
 
+class SlowTiltTrainer(TiltTrainer):
+    """... whose optimiser step takes a while (stands in for the GPU time of a real policy_update): what the other ranks
+    do meanwhile is what tests/test_pipeline_dist.py looks at."""
+
+    def train_step(self, states, pis, zs, lr):
+        import time
+        time.sleep(0.6)
+        return TiltTrainer.train_step(self, states, pis, zs, lr)
+
+
+def main_async(out_dir):
+    """The asynchronous schedule on CPU ranks: rounds of a few engine steps, a trainer thread on rank 0 whose updates take
+    1.2 s each (two epochs of 0.6 s)."""
+    rank, world, _ = dist.init(backend="gloo")
+    conf = {"board_width": 8, "board_height": 8, "n_in_row": 4, "learn_rate": 2e-3, "lr_multiplier": 1.0, "temp": 1.0,
+            "n_playout": 8, "c_puct": 5, "buffer_size": 100000, "batch_size": 16, "epochs": 2, "kl_targ": 1e9,
+            "check_freq": 20, "eval_games": 2, "game_batch_num": 60, "play_batch_size": 1, "pure_mcts_playout_num": 10,
+            "async_update": True, "round_seconds": 0.15, "concurrent_games": 4,
+            "model_dir": os.path.join(out_dir, "models%d" % rank)}
+    net = TiltNet(64)
+    trainer = SlowTiltTrainer(net) if rank == 0 else None
+    pipe = TrainPipeline(conf, policy_value_net=net, seed=77, trainer=trainer, eval_net=TiltNet(64) if rank == 0 else None)
+    hist = pipe.run()
+    res = {"rank": rank, "world": world, "history": hist, "buffer": len(pipe.data_buffer),
+           "weight_broadcasts": pipe.weight_broadcasts, "weights_version": pipe.weights_version,
+           "updates_done": pipe.updates_done, "updates_skipped": pipe.updates_skipped,
+           "update_intervals": pipe.update_intervals, "round_log": pipe.round_log, "sets": net.sets,
+           "trainer_history": getattr(pipe, "trainer_history", []), "taken": pipe._taken,
+           "w": net.params()["w"].tolist(), "trainer_w": trainer.get_params()["w"].tolist() if trainer else None,
+           "game_indices": sorted(set(int(s.index) for s in pipe.engine.slots if s.active))}
+    with open(os.path.join(out_dir, "pipe%d.json" % rank), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    pipe.engine.close()
+    dist.shutdown()
+
+
 def main():
     out_dir = sys.argv[1]
     if len(sys.argv) > 2 and sys.argv[2] == "real":
         return main_real(out_dir)
+    if len(sys.argv) > 2 and sys.argv[2] == "async":
+        return main_async(out_dir)
+    ASYNC = False                 # the lock-step schedule: every rank waits for rank 0's update
     rank, world, _ = dist.init(backend="gloo")
     conf = {"board_width": 8, "board_height": 8, "n_in_row": 4, "learn_rate": 2e-3, "lr_multiplier": 1.0, "temp": 1.0,
             "n_playout": 8, "c_puct": 5, "buffer_size": 100000, "batch_size": 16, "epochs": 2, "kl_targ": 0.02,
-            "check_freq": 1000, "game_batch_num": 4, "play_batch_size": 2, "pure_mcts_playout_num": 10,
+            "check_freq": 1000, "game_batch_num": 4, "play_batch_size": 2, "pure_mcts_playout_num": 10, "async_update": ASYNC,
             "concurrent_games": 4, "model_dir": os.path.join(out_dir, "models%d" % rank)}
     net = TiltNet(64)
     trainer = TiltTrainer(net) if rank == 0 else None

@@ -36,7 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
     from alphapig_amd.policy_value_net import PolicyValueNet
     conf = {"board_width": 15, "board_height": 15, "n_in_row": 5, "learn_rate": 1e-3, "lr_multiplier": 1.0, "temp": 1.0,
             "n_playout": 6, "c_puct": 5, "buffer_size": 100000, "batch_size": 32, "epochs": 2, "kl_targ": 0.02,
-            "check_freq": 1000, "game_batch_num": 3, "play_batch_size": 2, "pure_mcts_playout_num": 10,
+            "check_freq": 1000, "game_batch_num": 3, "play_batch_size": 2, "pure_mcts_playout_num": 10, "async_update": False,
             "concurrent_games": 16, "n_blocks": 1, "n_filter": 128}
     pipe = TrainPipeline(conf, device=0, seed=3)
     assert pipe.distributed and pipe.world == 1

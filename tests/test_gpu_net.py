@@ -330,6 +330,10 @@ def _net_with_trunk_kernel(kind, prm, n_blocks, batch):
     """kind "ring" = the direct convolution (trunk15_ring_kernel: exact fp32 FMA chains, the in-tree cross-check), "wino3" = the
     fused F(4x4,3x3) Winograd kernel (default); selected through the C ABI's test hook apz_test_select_trunk."""
     from alphapig_amd.policy_value_net import PolicyValueNet
+    if kind == "wino3b":      # the 3 x bf16 split kernel (constructor flag), forced onto batches of every size
+        net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm, trunk_arith="bf16x3")
+        net._ck(net.L.apz_test_select_trunk(net._h, 4))
+        return net
     net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm)
     net._ck(net.L.apz_test_select_trunk(net._h, {"ring": 0, "wino3": 3, "wino3-batched": 4}[kind]))
     return net
@@ -495,3 +499,36 @@ def test_wino3_launch_shapes_do_not_change_a_boards_bits():
     o = net_ref.forward(prm, planes[:24], "resnet", 2, np.float64)
     np.testing.assert_allclose(big[0][:24], o[0], rtol=0, atol=LOGIT_ATOL)
     net.close()
+
+
+def test_bf16x3_trunk_10_blocks_512_boards_and_launch_shapes():
+    """The opt-in 3 x bf16 split trunk (csrc/trunk15_wino3b.h, PolicyValueNet(trunk_arith="bf16x3")) at the bench's launch
+    shape: 10 blocks, 512 boards in one forward, rows at both ends / around the middle / 26 random ones against the float64
+    oracle at north_star's 1e-4 (policy_value_net_mxnet.py:70-102) -- and a board's bits do not depend on the launch shape
+    (1 ... 300 boards, odd batches, fewer pairs than CUs), nor on its place in the batch."""
+    prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
+    net = _net_with_trunk_kernel("wino3b", prm, 10, 512)
+    _, planes = random_positions(512, 15, seed=4242)
+    logits, probs, vlog, vals = net.forward_with_logits(planes)
+    rows = sorted(set([0, 1, 255, 256, 510, 511]) | set(np.random.RandomState(9).permutation(512)[:26].tolist()))
+    o_logits, o_probs, o_vlog, o_vals = net_ref.forward(prm, planes[rows], "resnet", 10, np.float64)
+    np.testing.assert_allclose(logits[rows], o_logits, rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(vlog[rows], o_vlog[:, 0], rtol=0, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(probs[rows], o_probs, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(vals[rows], o_vals[:, 0], rtol=0, atol=2e-5)
+    for lo, n in ((0, 1), (3, 2), (10, 17), (40, 131), (100, 300)):
+        small = net.forward_with_logits(planes[lo:lo + n])
+        for a, b in zip(small, (logits, probs, vlog, vals)):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b)[lo:lo + n], err_msg="n=%d" % n)
+    perm = np.random.RandomState(0).permutation(512)
+    p2 = net.forward_with_logits(planes[perm])
+    np.testing.assert_array_equal(p2[0], logits[perm])
+    # without the test hook the constructor flag leaves batches of <= 32 boards on the exact-fp32 small-batch kernel
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    plain = PolicyValueNet(15, 15, batch_size=64, n_blocks=10, n_filter=128, model_params=prm)
+    flagged = PolicyValueNet(15, 15, batch_size=64, n_blocks=10, n_filter=128, model_params=prm, trunk_arith="bf16x3")
+    np.testing.assert_array_equal(plain.forward_with_logits(planes[:8])[0], flagged.forward_with_logits(planes[:8])[0])
+    big = flagged.forward_with_logits(planes[:64])[0]
+    np.testing.assert_allclose(big, logits[:64], rtol=0, atol=0)            # 64 boards: the split kernel, the same bits as in the 512 batch
+    for x in (net, plain, flagged):
+        x.close()

@@ -3,6 +3,7 @@ miniature).  Move parity is checked the way SURVEY.md section 7 prescribes: the 
 the GPU produced are recorded and replayed into the sequential CPU oracle, so both trees see the
 SAME numbers (batched-vs-batch-1 float drift cannot flip a PUCT near-tie), while the numbers
 themselves are checked against the float64 net oracle at 1e-4 / 2e-5 elsewhere."""
+import os
 import random
 
 import numpy as np
@@ -195,12 +196,54 @@ def test_train_pipeline_runs_a_few_batches():
     conf = dict(board_width=8, board_height=8, n_in_row=4, learn_rate=2e-3, lr_multiplier=1.0, temp=1.0,
                 n_playout=30, c_puct=5, buffer_size=5000, batch_size=64, epochs=2, kl_targ=0.02, check_freq=3,
                 pure_mcts_playout_num=30, game_batch_num=3, play_batch_size=2, concurrent_games=16, n_blocks=1,
-                n_filter=64, eval_games=4, model_dir="/tmp/apz_models_test")
+                n_filter=64, eval_games=4, model_dir="/tmp/apz_models_test", async_update=False)
     tp = TrainPipeline(conf, seed=3)
     hist = tp.run()
     assert len(hist) == 3 and "win_ratio" in hist[-1] and 0.0 <= hist[-1]["win_ratio"] <= 1.0
     assert any("loss" in h and np.isfinite(h["loss"]) for h in hist)
     assert tp._taken == 6 and len(tp.data_buffer) > 0
+    tp.close()
+
+
+def test_asynchronous_train_pipeline_on_the_gpu():
+    """The asynchronous schedule with the REAL pieces on one GPU (alphapig_amd/pipeline.py: train_mxnet.py:265-300 with
+    the update in a trainer thread): self-play rounds keep stepping while the HIP trainer updates on its own stream with
+    its own evaluator handle; every published version is installed into the self-play evaluator device to device, the
+    arena and a checkpoint run in the trainer thread, and after the final drain the self-play evaluator answers exactly
+    like the trainer's own."""
+    pytest.importorskip("torch")
+    from alphapig_amd.pipeline import TrainPipeline
+    conf = dict(board_width=15, board_height=15, n_in_row=5, learn_rate=1e-3, lr_multiplier=1.0, temp=1.0,
+                n_playout=12, c_puct=5, buffer_size=200000, batch_size=64, epochs=3, kl_targ=0.02, check_freq=25,
+                pure_mcts_playout_num=20, game_batch_num=60, play_batch_size=1, concurrent_games=64, n_blocks=2,
+                n_filter=128, eval_games=2, model_dir="/tmp/apz_models_async", async_update=True, round_seconds=0.1)
+    tp = TrainPipeline(conf, seed=5)
+    steps_log, run_steps = [], tp.engine.run_steps
+
+    def logged_run_steps(*a, **k):
+        import time
+        t0 = time.time()
+        r = run_steps(*a, **k)
+        steps_log.append((t0, time.time()))
+        return r
+    tp.engine.run_steps = logged_run_steps
+    hist = tp.run()
+    assert hist[-1]["games_collected"] >= 60 and tp._taken == hist[-1]["games_collected"]
+    assert tp.updates_done >= 2 and tp.updates_done + tp.updates_skipped <= hist[-1]["games_collected"]
+    versions = [h["version"] for h in hist]
+    assert versions == sorted(versions) and versions[-1] == tp.updates_done == tp.weights_version
+    assert tp.weight_broadcasts == len(set(v for v in versions if v > 0))
+    # self-play went on during the updates: engine steps (8 scheduler rounds per call) ran INSIDE update intervals
+    inside = sum(1 for a, b in tp.update_intervals for t0, t1 in steps_log if a < t0 and t1 < b)
+    assert inside >= 1, (tp.update_intervals[:3], steps_log[:5])
+    ups = [h for h in tp.trainer_history if "loss" in h]
+    assert ups and all(np.isfinite(h["loss"]) and np.isfinite(h["kl"]) for h in ups)
+    assert any("win_ratio" in h for h in tp.trainer_history) and os.path.exists("/tmp/apz_models_async/current_policy.model")
+    planes = (np.random.RandomState(2).rand(5, 9, 15, 15) < 0.2).astype(np.float32)
+    pa, va = tp.policy_value_net.policy_value(planes)          # installed from the last published snapshot
+    tp._async_trainer.sync_evaluator(tp._eval_net)
+    pb, vb = tp._eval_net.policy_value(planes)                 # the trainer's own evaluator on the trainer's weights
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb)
     tp.close()
 
 

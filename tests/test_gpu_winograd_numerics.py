@@ -143,3 +143,24 @@ def test_winograd_trunk_keeps_a_3x_margin_under_stress():
     for r in rows:
         assert r["wino3_logit_err_rel"] == r["wino3-batched_logit_err_rel"], r
         assert r["wino3_value_err_rel"] == r["wino3-batched_value_err_rel"], r
+
+
+def test_bf16x3_split_trunk_is_fp32_accurate_under_stress():
+    """trunk15_wino3b_kernel (opt-in, PolicyValueNet(trunk_arith="bf16x3")): the same Winograd convolution with every fp32
+    operand as three bf16 terms on the bf16 matrix pipe.  Gates: every row inside the same bound the fp32 Winograd kernel
+    is held to (1e-4 / 3, relative to the logit scale), and no worse than twice the DIRECT fp32 kernel's own error or --
+    where the Winograd transforms themselves dominate -- than 1.25 x the fp32 Winograd kernel's (the table holds all
+    three).  policy_value_net_mxnet.py:77-83 over the 10-block net."""
+    kinds = ("wino3b", "wino3-batched", "ring")
+    rows = _stress_table(kinds)
+    _write_table("r04_winograd_numerics_bf16x3.json", kinds, rows)
+
+    def bound(r, key):
+        exploding = r["logit_scale"] > 1e3
+        return max(TOL, 4.0 * r["ring_" + key]) if exploding else TOL
+    bad = [r for r in rows if r["wino3b_logit_err_rel"] > bound(r, "logit_err_rel") or
+           r["wino3b_value_err_rel"] > bound(r, "value_err_rel")]
+    assert not bad, bad
+    for r in rows:
+        for key in ("logit_err_rel", "value_err_rel"):
+            assert r["wino3b_" + key] <= max(2.0 * r["ring_" + key], 1.25 * r["wino3-batched_" + key], 1e-6), (key, r)

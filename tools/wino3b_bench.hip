@@ -109,6 +109,17 @@ int main(int argc, char** argv) {
     for (auto& v : hb) v = ((rand() % 2000) - 1000) * 1e-4f;
     CK(hipMemcpy(bias, hb.data(), 512, hipMemcpyHostToDevice));
 
+    if (getenv("APZ_PROFILE")) {          // rocprofv3 runs: 12 launches of each variant at 512 boards, nothing else
+        for (int it = 0; it < 12; it++) {
+            hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
+            hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
+            hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(256), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, 512);
+            hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(256), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, 512);
+        }
+        CK(hipDeviceSynchronize());
+        printf("RESULT PROFILE\n");
+        return 0;
+    }
     // ---- cross-check against the naive double kernel at ragged sizes
     int bad = 0;
     const int check_sizes[7] = {1, 7, 64, 96, 512, 515, 1030};
@@ -123,10 +134,10 @@ int main(int argc, char** argv) {
             CK(hipMemset(out2, 0xff, cnt * 4));
             hipLaunchKernelGGL(wino_ref_kernel, dim3((unsigned)((n * 128 * 16 + 255) / 256)), dim3(256), 0, 0, in, upk, bias, res, outd, n, resid);
             if (resid) {
-                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
                 hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
             } else {
-                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
                 hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
             }
             CK(hipGetLastError());
@@ -171,8 +182,8 @@ int main(int argc, char** argv) {
                     for (int it = -3; it < iters; it++) {
                         if (it == 0) CK(hipEventRecord(e0, 0));
                         if (kern == 0) {
-                            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
-                            else hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                            else hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
                         } else {
                             if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
                             else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
@@ -191,11 +202,11 @@ int main(int argc, char** argv) {
     }
 #ifdef APZ_WINO3B_STAMPS
     {
-        unsigned long long st[4 * 4 * 8];
-        hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(256), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
+        unsigned long long st[4 * 8 * 8];
+        hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(apz::apz_wino3b_stamps), sizeof st));
-        for (int w = 0; w < 4; w++)
+        for (int w = 0; w < 8; w++)
             printf("stamps wg0 wave %d: prologue %llu barriers %llu chunks %llu epilogue %llu total %llu cycles\n", w, st[w * 8 + 0], st[w * 8 + 1],
                    st[w * 8 + 2], st[w * 8 + 3], st[w * 8 + 7]);
     }
