@@ -84,6 +84,7 @@ def host():
         "apzh_root_visits_dense": (C.c_int, [vp, i32p, C.c_int, i32p, i32p]),
         "apzh_update_with_move": (C.c_int, [vp, C.c_int, C.c_int]),
         "apzh_play_move": (C.c_int, [vp, C.c_int, C.c_int, i32p]),
+        "apzh_play_moves": (C.c_int, [vp, i32p, C.c_int, i32p, u8p, i32p, i32p]),
         "apzh_stats": (C.c_int, [vp, C.c_int, i64p]),
         "apzh_pool_info": (C.c_int, [vp, i64p]),
         "apzh_pure_get_move": (C.c_int, [vp, C.c_int, u32p, i32p, i32p, i64p, f64p, C.c_int, i32p]),
@@ -106,7 +107,7 @@ HOST_SYMBOLS = ["apzh_last_error", "apzh_version", "apzh_create", "apzh_destroy"
                 "apzh_game_has_a_winner", "apzh_code_stride", "apzh_game_codes", "apzh_codes_to_planes",
                 "apzh_advance", "apzh_feed", "apzh_feed_sparse", "apzh_pending_path", "apzh_playouts_done",
                 "apzh_set_playouts_done", "apzh_set_n_playout", "apzh_node_children", "apzh_set_prior_mode",
-                "apzh_root_visits_dense", "apzh_update_with_move", "apzh_play_move", "apzh_stats",
+                "apzh_root_visits_dense", "apzh_update_with_move", "apzh_play_move", "apzh_play_moves", "apzh_stats",
                 "apzh_pool_info", "apzh_pure_get_move", "apzh_mt_seed", "apzh_np_sum", "apzh_root_sample",
                 "apzh_pretouch_limit_gb"]
 

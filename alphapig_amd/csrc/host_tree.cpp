@@ -858,6 +858,35 @@ int apzh_play_move(apzh_pool *p, int gi, int move, int32_t *out3) {
     return APZH_OK;
 }
 
+int apzh_play_moves(apzh_pool *p, const int32_t *games, int n, const int32_t *moves, uint8_t *codes_before,
+                    int32_t *movers_before, int32_t *out3) {
+    if (!p || !games || !moves || !out3 || n < 0) return fail(APZH_E_ARG, "null argument");
+    const int stride = apzh_code_stride(p->cfg.height, p->cfg.width);
+    for (int i = 0; i < n; i++) {
+        if (games[i] < 0 || games[i] >= (int)p->games.size()) return fail(APZH_E_ARG, "game index out of range");
+        if (p->games[games[i]].pending) return fail(APZH_E_STATE, "a leaf is pending");
+    }
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(p->nthreads) if (n > 8)
+    for (int i = 0; i < n; i++) {
+        Game &g = p->games[games[i]];
+        if (codes_before) write_codes(p, g, g.current_player, (int)g.hist_move.size(), codes_before + (size_t)i * stride);
+        if (movers_before) movers_before[i] = g.current_player;
+        if (board_do_move(p, g, moves[i])) {
+#pragma omp atomic write
+            bad = 1;
+            continue;
+        }
+        reroot(g, moves[i]);
+        g.playouts_done = 0;
+        bool ended; int winner;
+        end_after_move(p, g.cells.data(), (int)g.hist_move.size(), moves[i], (int8_t)(3 - g.current_player), &ended, &winner);
+        out3[3 * i] = ended ? 1 : 0; out3[3 * i + 1] = winner; out3[3 * i + 2] = (int32_t)g.hist_move.size();
+    }
+    if (bad) return fail(APZH_E_ARG, "illegal move");
+    return APZH_OK;
+}
+
 int apzh_stats(apzh_pool *p, int gi, int64_t *out4) {
     CHECK_GAME(p, gi);
     Game &g = p->games[gi];

@@ -205,14 +205,17 @@ class SelfPlayEngine(object):
             temps = np.array([self._temp_for(len(self.slots[int(s)].movers)) for s in ready], dtype=np.float64)
             pis, moves = sample_moves(self.rng_bank, ready, visits, temps, alpha=self.noise_alpha, eps=self.noise_eps,
                                       with_noise=True, want_pi=True, n_threads=self._sample_threads)
-            for pi, move, s in zip(pis, moves, ready):
-                s = int(s)
-                self._record(s, pi)
-                ended, winner, _ = self.pool.play_move(s, int(move))
-                self.stats["moves"] += 1
-                if ended:
-                    self._finish_game(s, winner)
-                    self._start_game(s)
+            # record (state, pi, player) and play the move of every ready game in one native call
+            codes_b, movers_b, ended_b, winner_b = self.pool.play_moves(ready, moves)
+            self.stats["moves"] += len(ready)
+            for i, s in enumerate(ready):
+                slot = self.slots[int(s)]
+                slot.codes.append(codes_b[i])
+                slot.pis.append(pis[i])
+                slot.movers.append(int(movers_b[i]))
+                if ended_b[i]:
+                    self._finish_game(int(s), int(winner_b[i]))
+                    self._start_game(int(s))
             return
         for row, s in zip(visits, ready):
             s = int(s)

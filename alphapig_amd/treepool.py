@@ -177,6 +177,19 @@ class TreePool(object):
         self._ck(self.L.apzh_play_move(self._h, g, int(move), as_ptr(out, C.c_int32)))
         return bool(out[0]), int(out[1]), int(out[2])
 
+    def play_moves(self, games, moves):
+        """play_move for several different games at once -> (codes_before uint8 [n, stride], movers_before int32 [n],
+        ended bool [n], winner int32 [n]): the recorded (state, player) of each ply and the outcome of the move."""
+        ids = np.ascontiguousarray(games, dtype=np.int32)
+        mv = np.ascontiguousarray(moves, dtype=np.int32)
+        n = len(ids)
+        codes = np.zeros((n, self.code_stride), dtype=np.uint8)
+        movers = np.zeros(n, dtype=np.int32)
+        out = np.zeros((n, 3), dtype=np.int32)
+        self._ck(self.L.apzh_play_moves(self._h, as_ptr(ids, C.c_int32), n, as_ptr(mv, C.c_int32), as_ptr(codes, C.c_uint8),
+                                        as_ptr(movers, C.c_int32), as_ptr(out, C.c_int32)))
+        return codes, movers, out[:, 0].astype(bool), out[:, 1]
+
     def stats(self, g):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.apzh_stats(self._h, g, as_ptr(out, C.c_int64)))

@@ -126,6 +126,11 @@ int apzh_root_visits_dense(apzh_pool *p, const int32_t *games, int n, int32_t *v
 int apzh_update_with_move(apzh_pool *p, int g, int move);
 /* do_move + update_with_move(move) + playouts_done=0; out3: ended, winner, n_moves */
 int apzh_play_move(apzh_pool *p, int g, int move, int32_t *out3);
+/* apzh_play_move for n DIFFERENT games in one call (OpenMP over games): game games[i] plays moves[i].  codes_before
+ * [n][stride] / movers_before[n] (either may be NULL) receive the position codes and the player to move BEFORE the move --
+ * the (state, player) the reference records per ply (game_ai.py:118-122); out3[n][3] as apzh_play_move. */
+int apzh_play_moves(apzh_pool *p, const int32_t *games, int n, const int32_t *moves, uint8_t *codes_before,
+                    int32_t *movers_before, int32_t *out3);
 /* counters: out[0]=net leaf evals out[1]=terminal leaf playouts out[2]=live nodes out[3]=peak nodes */
 int apzh_stats(apzh_pool *p, int g, int64_t *out4);
 /* pool-wide: out[0]=bytes reserved for the tree arenas, out[1]=1 if they were pre-touched at creation,
