@@ -428,6 +428,9 @@ def main():
                     help="declared UNTIMED GPU-only pre-warm before the W warm-up steps: dummy forwards of empty boards "
                          "(not engine steps) for this many seconds, plus 4 dummy forwards queued right before the closing "
                          "synchronisation of the warm-up so that the timed region starts on a GPU at its running clocks; 0 = off")
+    ap.add_argument("--only-bf16x3", action="store_true",
+                    help="run ONLY the trunk_bf16x3 extra object (the opt-in split kernel's engine run) and print it: the command "
+                         "its rocprofv3 trace is taken of (tools/r04_measure.sh)")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (gloo, stand-in evaluator from tests/fakenet.py, "
                          "8 games per rank); the JSON line is marked invalid and is NOT a measurement")
@@ -437,6 +440,12 @@ def main():
         print(json.dumps({"n": n_, "dt": dt_, "isa": isa_}))
         return
 
+    if args.only_bf16x3:
+        mean_plies, _ = load_mean_plies()
+        obj = bf16x3_line(0, max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), host_cpu_share())), args.games, args.pipeline,
+                          mean_plies, steps=args.steps if args.steps != 1200 else 120, warmup=args.warmup if args.warmup != 100 else 30)
+        print(json.dumps(obj))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:], deadline_s=args.deadline_s, silence_s=args.rank_silence_s,
                            early_exit_grace_s=args.early_exit_grace_s)     # before anything touches the GPU
