@@ -416,16 +416,12 @@ int launch_wino3b_t(apz_engine* e, int attr_slot, const ConvLayer& L, const floa
                                     T::LDS_BYTES));
         configured = true;
     }
-    if (!e->zeros256) {
-        HIP_TRY(hipMalloc((void**)&e->zeros256, 256 * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(e->zeros256, 0, 256 * sizeof(float), e->stream));
-    }
     for (int b0 = 0; b0 < n; b0 += WINO3_MAX_BOARDS) {
         const int nb = std::min(n - b0, WINO3_MAX_BOARDS);
         const size_t off = (size_t)b0 * T::C * T::GPLANE;
         const int grid = apz::wino3_grid(nb, e->num_cu);
         hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<RESID, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in + off,
-                           (const void*)L.upk3b, L.bias, RESID ? resid + off : nullptr, out + off, nb, (const float*)e->zeros256);
+                           (const void*)L.upk3b, L.bias, RESID ? resid + off : nullptr, out + off, nb);
     }
     HIP_TRY(hipGetLastError());
     return APZ_OK;

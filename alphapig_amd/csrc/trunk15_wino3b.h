@@ -119,11 +119,10 @@ inline void wino3b_pack_host(F u_of, std::vector<uint16_t>& out) {
 __device__ unsigned long long apz_wino3b_stamps[4 * 8 * 8];   // [workgroup 4][wave 8][phase 8]
 #endif
 
-// zeros: at least 64 bytes of 0.0f in device memory (lanes 60..63 of a plane copy take row 15 of the tile from there)
 template <bool RESID, bool RELU = true>
 __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __restrict__ in, const void* __restrict__ upk,
                                                              const float* __restrict__ bias, const float* __restrict__ resid,
-                                                             float* __restrict__ out, int n, const float* __restrict__ zeros) {
+                                                             float* __restrict__ out, int n) {
     using T = Wino3B;
 #ifdef APZ_WINO3B_STAMPS
     // phases: 0 item prologue, 1 barrier waits, 2 chunk bodies, 3 epilogue, 7 total
@@ -174,14 +173,18 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, 0);
     };
 
-    // ---- staging role: wave w brings planes w (board 0) and w + 8 (board 1) of a chunk into LDS by LDS-DMA: one
-    // instruction per plane, lane l copies 16 bytes from its global address to LDS byte m0 + 16 l (lanes 60..63 copy
-    // zeros: row 15 of the tile; no branch, the chunk body stays one scheduling region).  Inline assembly: hipcc's
+    // ---- staging role: wave w brings planes w (board 0) and w + 8 (board 1) of a chunk into LDS by LDS-DMA
+    // (buffer_load_dwordx4 ... lds): one instruction per plane, lane l copies 16 bytes to LDS byte m0 + 16 l (lanes 60..63
+    // are out of range: row 15 of the tile stays zero; no branch, the chunk body stays one scheduling region).  Inline assembly: hipcc's
     // wait-count insertion does not see these loads (it would drain the weight ring in front of every LDS read that might
     // alias a DMA destination).  They need no wait of their own: a plane requested in slot 1 of a chunk is older than the
     // weight loads issued behind it, whose data the MFMAs of a later slot wait for -- vector memory operations complete in
     // order -- and the tile is first read behind the next chunk's barrier.
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)rawb;   // LDS byte address of rawb
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    const unsigned long long in_a = (unsigned long long)in;
+    const i32x4_ dma_rsrc = {(int)(unsigned)(in_a & 0xffffffffull), (int)(unsigned)((in_a >> 32) & 0xffffull), (int)act_bytes, 0x00020000};
+    const unsigned dma_vo = lane < 60 ? lane * 16 : 0x80000000u;   // lanes 60..63: out of range (row 15 of the tile stays zero)
     auto raw_dma = [&](int t, int c, int par) {       // chunk c (clamped) of item t -> raw[par]
         c = c < T::NCHUNK ? c : T::NCHUNK - 1;
         const int bd0_ = 2 * item_pair(t);
@@ -190,9 +193,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
             const int plane = 8 * j + wave;           // board j, channel `wave`
             const int bdp = bd0_ + j;
             const int bd = bdp < n ? bdp : n - 1;
-            const float* src = lane < 60 ? in + (size_t)(bd * T::C + c * T::CK + wave) * T::GPLANE + lane * 4 : zeros + (lane - 60) * 4;
+            const unsigned so = (unsigned)(bd * T::C + c * T::CK + wave) * plane_b;
             const unsigned dst = lds0 + (unsigned)(par * T::RAW_FLOATS + T::RFRONT + plane * T::RPS) * 4;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(dma_vo), "s"(dma_rsrc), "s"(dst), "s"(so) : "memory");
         }
     };
 

@@ -47,7 +47,7 @@ N_PLAYOUT = 400
 N_BLOCKS = 10
 N_FILTER = 128
 GAMES_PER_GPU = 1024
-CALIB = os.path.join(REPO, "profiles", "calibration_r03.json")
+CALIB = os.path.join(REPO, "profiles", "calibration_r04.json")
 FP32_MATRIX_PEAK_TF = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA peak
 BF16_MATRIX_PEAK_TF = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
 HBM_PEAK_GBS = 8000.0
@@ -61,7 +61,7 @@ def load_mean_plies():
     if os.path.exists(CALIB):
         with open(CALIB) as f:
             c = json.load(f)
-        return float(c["mean_plies_per_game"]), "profiles/calibration_r03.json (%d complete games counted in steady state, MI355X)" % c["games"]
+        return float(c["mean_plies_per_game"]), "profiles/calibration_r04.json (%d complete games counted in steady state, MI355X)" % c["games"]
     return None, None
 
 
@@ -585,7 +585,7 @@ def main():
             ln.close()
         return
     if mean_plies is None:
-        raise SystemExit("profiles/calibration_r03.json missing: run `python bench.py --count-games 240` once")
+        raise SystemExit("profiles/calibration_r04.json missing: run `python bench.py --count-games 240` once")
 
     import gc
     gc.collect()

@@ -532,3 +532,32 @@ def test_bf16x3_trunk_10_blocks_512_boards_and_launch_shapes():
     np.testing.assert_allclose(big, logits[:64], rtol=0, atol=0)            # 64 boards: the split kernel, the same bits as in the 512 batch
     for x in (net, plain, flagged):
         x.close()
+
+
+def test_bf16x3_weights_packed_on_the_device_equal_the_host_pack():
+    """The trainer's refresh path (apz_load_weights_dev, policy_value_net_mxnet.py:295-297) packs the three bf16 terms of
+    U = G g G^T with a kernel; the constructor packs them on the host.  Same double arithmetic, same rounding: the two
+    evaluators give identical bits -- also after the weights change."""
+    torch = pytest.importorskip("torch")
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=31, style="bench")
+    prm2 = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=32, style="bench")
+    _, planes = random_positions(70, 15, seed=77)
+    host = PolicyValueNet(15, 15, batch_size=128, n_blocks=3, n_filter=128, model_params=prm, trunk_arith="bf16x3")
+    dev = PolicyValueNet(15, 15, batch_size=128, n_blocks=3, n_filter=128, model_params=prm2, trunk_arith="bf16x3")
+    tensors = {k: torch.tensor(np.ascontiguousarray(v, dtype=np.float32), device="cuda") for k, v in prm.items()}
+    dev.load_device_params(tensors)
+    a, b = host.forward_with_logits(planes), dev.forward_with_logits(planes)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    o = net_ref.forward(prm, planes[:16], "resnet", 3, np.float64)
+    np.testing.assert_allclose(a[0][:16], o[0], rtol=0, atol=LOGIT_ATOL)
+    host.set_params(prm2)                                       # and the host path again, on the other weights
+    tensors2 = {k: torch.tensor(np.ascontiguousarray(v, dtype=np.float32), device="cuda") for k, v in prm2.items()}
+    dev.load_device_params(tensors2)
+    for x, y in zip(host.forward_with_logits(planes), dev.forward_with_logits(planes)):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    with pytest.raises(Exception):                              # the arithmetic is chosen before the weights are loaded
+        host._ck(host.L.apz_set_trunk_arith(host._h, 0))
+    host.close()
+    dev.close()

@@ -5,6 +5,7 @@
 set -o pipefail
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
+rm -rf $OUT   # (gpurun merges files back into the local gpurun_out/: stale traces of earlier runs would be summarised along)
 mkdir -p $OUT
 export TMPDIR=/tmp
 STEPS=${STEPS:-40}

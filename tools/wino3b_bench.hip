@@ -75,9 +75,8 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TB::LDS_BYTES));
     const int nmax = 2048;
     const size_t act = (size_t)nmax * 128 * 240;
-    float *in, *res, *out, *out2, *upk, *bias, *zeros;
+    float *in, *res, *out, *out2, *upk, *bias;
     double* outd;
-    CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256));
     void* upkb;
     CK(hipMalloc(&in, act * 4)); CK(hipMalloc(&res, act * 4)); CK(hipMalloc(&out, act * 4)); CK(hipMalloc(&out2, act * 4));
     const int nref = 1030;
@@ -111,8 +110,8 @@ int main(int argc, char** argv) {
 
     if (getenv("APZ_PROFILE")) {          // rocprofv3 runs: 12 launches of each variant at 512 boards, nothing else
         for (int it = 0; it < 12; it++) {
-            hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
-            hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
+            hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512);
+            hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512);
             hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(256), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, 512);
             hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(256), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, 512);
         }
@@ -134,10 +133,10 @@ int main(int argc, char** argv) {
             CK(hipMemset(out2, 0xff, cnt * 4));
             hipLaunchKernelGGL(wino_ref_kernel, dim3((unsigned)((n * 128 * 16 + 255) / 256)), dim3(256), 0, 0, in, upk, bias, res, outd, n, resid);
             if (resid) {
-                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n);
                 hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
             } else {
-                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n);
                 hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
             }
             CK(hipGetLastError());
@@ -182,8 +181,8 @@ int main(int argc, char** argv) {
                     for (int it = -3; it < iters; it++) {
                         if (it == 0) CK(hipEventRecord(e0, 0));
                         if (kern == 0) {
-                            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
-                            else hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n, zeros);
+                            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n);
+                            else hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n);
                         } else {
                             if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
                             else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
@@ -203,7 +202,7 @@ int main(int argc, char** argv) {
 #ifdef APZ_WINO3B_STAMPS
     {
         unsigned long long st[4 * 8 * 8];
-        hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512, zeros);
+        hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512);
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(apz::apz_wino3b_stamps), sizeof st));
         for (int w = 0; w < 8; w++)
