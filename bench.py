@@ -676,7 +676,7 @@ def main():
     # HBM / fabric traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
     # (cannot be collected from inside the process), committed under profiles/
     traffic, traffic_src = None, None
-    for tname in ("r03_trunk_traffic.json", "r02_trunk_traffic.json"):
+    for tname in ("r04_trunk_traffic.json", "r03_trunk_traffic.json", "r02_trunk_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if os.path.exists(tpath):
             with open(tpath) as f:
