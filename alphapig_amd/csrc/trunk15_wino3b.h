@@ -255,21 +255,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
                     const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
                     xr[i][0] = c03[0]; xr[i][1] = c03[1]; xr[i][2] = c03[2]; xr[i][3] = c03[3];
                 } else {
-#ifndef APZB_HALO128
-#define APZB_HALO128 1
-#endif
-#if APZB_HALO128
-                    // the halo columns as the last / first element of the neighbouring 16-byte quads: such reads are conflict
-                    // free like the centre quad's (a 4-byte read of this lane pattern is 4-way bank conflicted)
-                    // (the empty asm keeps hipcc from narrowing the load to the one element that is used)
-                    f32x4 ql = *reinterpret_cast<const f32x4*>(rp + i * T::RROW - 4), qr = *reinterpret_cast<const f32x4*>(rp + i * T::RROW + 4);
-                    asm volatile("" : "+v"(ql), "+v"(qr));
-                    xr[i][0] = ql[3];
-                    xr[i][1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, qr[0]) & col16_mask);
-#else
                     xr[i][0] = rp[i * T::RROW - 1];
                     xr[i][1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rp[i * T::RROW + 4]) & col16_mask);   // (no branch)
-#endif
                 }
             }
 #pragma unroll
