@@ -138,6 +138,7 @@ struct apz_engine {
     unsigned* w3s_tickets = nullptr;         // ... and the pairs' ticket words (each launch exchanges its epoch in: trunk15_wino3s.h)
     unsigned w3s_epoch = 0;                  // last epoch handed out; never 0, never repeated between two memsets of the words
     bool no_small_trunk = false;             // apz_test_select_trunk(APZ_TRUNK_WINOGRAD_BATCHED): tests compare the two forms
+    bool no_quarter_trunk = false;           // apz_test_select_trunk(APZ_TRUNK_WINOGRAD_NO_QUARTER): 64-channel items for every batch
     int trunk_arith = APZ_ARITH_F32;         // apz_set_trunk_arith: APZ_ARITH_BF16X3 = trunk15_wino3b_kernel for batches > 32
     int trunk_kernel = APZ_TRUNK_WINOGRAD;   // or APZ_TRUNK_DIRECT (trunk15_ring_kernel): apz_test_select_trunk, tests only
     // profiling
@@ -373,6 +374,8 @@ int launch_wino3_t(apz_engine* e, int attr_slot, const float* in, const float* u
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<RESID, RELU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<RESID, RELU, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3s_kernel<RESID, RELU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, apz::Wino3S::LDS_BYTES));
         configured = true;
@@ -398,9 +401,14 @@ int launch_wino3_t(apz_engine* e, int attr_slot, const float* in, const float* u
     for (int b0 = 0; b0 < n; b0 += WINO3_MAX_BOARDS) {
         const int nb = std::min(n - b0, WINO3_MAX_BOARDS);
         const size_t off = (size_t)b0 * T::C * T::GPLANE;
-        const int grid = apz::wino3_grid(nb, e->num_cu);      // persistent workgroups; item = board pair x channel half
-        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<RESID, RELU>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in + off,
-                           upk, bias, RESID ? resid + off : nullptr, out + off, nb);
+        bool quarter = false;                                 // few pairs (training batch 128, arena): four workgroups per pair
+        const int grid = apz::wino3_grid(nb, e->num_cu, e->no_quarter_trunk ? nullptr : &quarter);   // persistent workgroups; item = board pair x channel half (quarter)
+        if (quarter)
+            hipLaunchKernelGGL((apz::trunk15_wino3_kernel<RESID, RELU, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream,
+                               in + off, upk, bias, RESID ? resid + off : nullptr, out + off, nb);
+        else
+            hipLaunchKernelGGL((apz::trunk15_wino3_kernel<RESID, RELU>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in + off,
+                               upk, bias, RESID ? resid + off : nullptr, out + off, nb);
     }
     HIP_TRY(hipGetLastError());
     return APZ_OK;
@@ -1888,12 +1896,14 @@ int apz_set_trunk_arith(apz_engine* e, int arith) {
 }
 
 int apz_test_select_trunk(apz_engine* e, int kind) {
-    if (!e || (kind != APZ_TRUNK_WINOGRAD && kind != APZ_TRUNK_DIRECT && kind != APZ_TRUNK_WINOGRAD_BATCHED))
+    if (!e || (kind != APZ_TRUNK_WINOGRAD && kind != APZ_TRUNK_DIRECT && kind != APZ_TRUNK_WINOGRAD_BATCHED &&
+               kind != APZ_TRUNK_WINOGRAD_NO_QUARTER))
         return fail(APZ_E_ARG, "bad trunk kernel kind");
     EngineLock guard(e->submit_lock);
     if (!e->ring) return fail(APZ_E_UNSUPPORTED, "only the 15x15 / 128-filter residual net has two trunk kernels");
     e->trunk_kernel = kind == APZ_TRUNK_DIRECT ? APZ_TRUNK_DIRECT : APZ_TRUNK_WINOGRAD;
-    e->no_small_trunk = kind == APZ_TRUNK_WINOGRAD_BATCHED;
+    e->no_small_trunk = kind == APZ_TRUNK_WINOGRAD_BATCHED || kind == APZ_TRUNK_WINOGRAD_NO_QUARTER;
+    e->no_quarter_trunk = kind == APZ_TRUNK_WINOGRAD_NO_QUARTER;
     return APZ_OK;
 }
 

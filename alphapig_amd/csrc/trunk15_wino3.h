@@ -91,7 +91,13 @@ __device__ unsigned long long apz_wino3_stamps[4 * 8 * 8];
 #endif
 
 // RELU = false: the plain convolution + bias (training graph: forward before BatchNorm, data gradient)
-template <bool RESID, bool RELU = true>
+// QUARTER (round 4): work item = (board pair, 32 output channels) -- four workgroups per pair, for batches with fewer pairs
+// than a quarter of the CUs (the reference's training batch of 128, a 64-match arena): wave = (16-channel tile w & 1, board
+// (w >> 1) & 1, row half w >> 2) with 18 x 4 = 72 accumulators; a weight fragment feeds ONE MFMA per wave (the two board
+// waves of a tile fetch the same fragment: L1), the input transform is unchanged (all eight waves, both boards).  The two row
+// halves of a (tile, board) meet through X as before: wave ph = 0 finishes channel sub-steps 0, 1, wave ph = 1 sub-steps 2, 3.
+// Same MFMA order per output, same transform and epilogue formulas: the same bits as the 64-channel items.
+template <bool RESID, bool RELU = true, bool QUARTER = false>
 __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restrict__ in, const float* __restrict__ upk,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out,
@@ -121,7 +127,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, j = lane & 15;
-    const int ct = wave & 3;
+    const int ct = QUARTER ? (wave & 1) : (wave & 3);          // 16-channel tile of the item
+    const int bsel = (wave >> 1) & 1;                          // QUARTER: this wave's board
 
 
     // ---- work items of this workgroup.  Item = (board pair, channel half h).
@@ -132,16 +139,18 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     // duo:   block b -> XCD group c = b % 8, i = b / 8; duo d = (i / 2) * 8 + c takes pairs d, d + G/2, ...; h = i & 1.
     // plain: block b takes pairs b, b + G, ... and both halves of each.
     const int npairs = (n + 1) >> 1, G_ = (int)gridDim.x, b_ = (int)blockIdx.x;
-    const bool duo = (G_ & 15) == 0;
-    const int pair0 = duo ? ((b_ >> 4) * 8 + (b_ & 7)) : b_;
-    const int pstride = duo ? (G_ >> 1) : G_;
-    const int h_fix = (b_ >> 3) & 1;            // duo mode: this workgroup's channel half
+    // QUARTER: the same with four channel quarters: grids that are a multiple of 32 put the quarters of a pair on blocks
+    // b, b + 8, b + 16, b + 24 (one XCD); any other grid gives a workgroup whole pairs, quarter after quarter.
+    const bool duo = QUARTER ? (G_ & 31) == 0 : (G_ & 15) == 0;
+    const int pair0 = duo ? (QUARTER ? ((b_ >> 5) * 8 + (b_ & 7)) : ((b_ >> 4) * 8 + (b_ & 7))) : b_;
+    const int pstride = duo ? (QUARTER ? (G_ >> 2) : (G_ >> 1)) : G_;
+    const int h_fix = QUARTER ? ((b_ >> 3) & 3) : ((b_ >> 3) & 1);   // duo mode: this workgroup's channel half (quarter)
     const int np = pair0 < npairs ? (npairs - pair0 + pstride - 1) / pstride : 0;   // board pairs of this workgroup
-    const int nitems = duo ? np : 2 * np;
+    const int nitems = duo ? np : (QUARTER ? 4 : 2) * np;
     const int total_iters = nitems * T::NCHUNK;
     if (np == 0) return;                        // (uniform, before any barrier)
-    auto item_pair = [&](int t) { return pair0 + (duo ? t : (t >> 1)) * pstride; };
-    auto item_half = [&](int t) { return duo ? h_fix : (t & 1); };
+    auto item_pair = [&](int t) { return pair0 + (duo ? t : (QUARTER ? (t >> 2) : (t >> 1))) * pstride; };
+    auto item_half = [&](int t) { return duo ? h_fix : (QUARTER ? (t & 3) : (t & 1)); };   // channel half (QUARTER: quarter)
 
     // All global memory traffic goes through raw buffer instructions: descriptor (SGPRs) + per-lane 32-bit offset
     // + wave-uniform SGPR offset.  No 64-bit per-lane addresses (registers, VALU), and lanes that must not take
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     const unsigned ulane = lane * (T::UROW * 4);
     auto uload = [&](int ks, int v) {           // ks = global k-step of this workgroup's stream (32 per item), v = piece 0..4
         const int hh = item_half(ks >> 5), kk = ks & 31;
-        const unsigned so = (unsigned)(((hh * 4 + ct) * 2 + ph) * 32 + kk) * (T::USTEP * 4);
+        const unsigned so = (unsigned)((((QUARTER ? 2 : 4) * hh + ct) * 2 + ph) * 32 + kk) * (T::USTEP * 4);
         if (v == 4) {                           // values 16, 17 (+ 2 pad floats that are never loaded: dead registers under an
             const auto w = __builtin_amdgcn_raw_buffer_load_b64(r_u, ulane + 64, so, 0);   // in-flight load get reused -> WAW waits)
             const f32x2 f = __builtin_bit_cast(f32x2, w);
@@ -337,18 +346,18 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #if APZ3_EARLY_BARRIER
     __syncthreads();                                // V[0] (chunk 0) complete
     {
-        const float* vp0 = vb + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+        const float* vp0 = vb + (9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0);
         bc0 = *reinterpret_cast<const f32x2*>(vp0);
-        bc1 = *reinterpret_cast<const f32x2*>(vp0 + 256);
+        if (!QUARTER) bc1 = *reinterpret_cast<const f32x2*>(vp0 + 256);
     }
 #endif
     for (int t = 0; t < nitems; t++) {
         const int h = item_half(t);
         const int bd0 = 2 * item_pair(t);
         const bool two = bd0 + 1 < n;           // the last pair of an odd batch has one board (computed twice, stored once)
-        f32x4 acc[2][18];
+        f32x4 acc[QUARTER ? 1 : 2][18];
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < (QUARTER ? 1 : 2); b++)
 #pragma unroll
             for (int p = 0; p < 18; p++) acc[b][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -383,15 +392,15 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #endif
         auto chunk = [&](int g, auto PAR) {
             constexpr int par = decltype(PAR)::value;
-            const float* vp = vb + par * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+            const float* vp = vb + par * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0);   // QUARTER: own board only
             // APZ3_EARLY_BARRIER: the chunk's barrier sits between slots 16 and 17 of the PREVIOUS chunk (see there) and
             // bc0 / bc1 already hold this chunk's first operands.
-            const float* vpn = vb + (1 - par) * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2;
+            const float* vpn = vb + (1 - par) * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0);
 #if !APZ3_EARLY_BARRIER
             __syncthreads();                    // V[par] complete, V[1-par] and raw[par] free, raw[1-par] visible
             APZ3_STAMP(1)
             bc0 = *reinterpret_cast<const f32x2*>(vp);
-            bc1 = *reinterpret_cast<const f32x2*>(vp + 256);
+            if (!QUARTER) bc1 = *reinterpret_cast<const f32x2*>(vp + 256);
 #endif
 #define APZ3_SLOT(k)                                                                                               \
             {                                                                                                      \
@@ -400,16 +409,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 f32x2 bn0 = bc0, bn1 = bc1;                                                                        \
                 if ((k) + 1 < 18) {                                                                                \
                     bn0 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + sn * 128);                            \
-                    bn1 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + 256 + sn * 128);                      \
+                    if (!QUARTER) bn1 = *reinterpret_cast<const f32x2*>(vp + mn * T::VPP + 256 + sn * 128);        \
                 } else if (APZ3_EARLY_BARRIER) {          /* the next chunk's first operands (V[1-par], complete) */ \
                     bn0 = *reinterpret_cast<const f32x2*>(vpn);                                                    \
-                    bn1 = *reinterpret_cast<const f32x2*>(vpn + 256);                                              \
+                    if (!QUARTER) bn1 = *reinterpret_cast<const f32x2*>(vpn + 256);                                \
                 }                                                                                                  \
                 const float a0 = ur[m >> 1][(2 * m) & 3], a1 = ur[m >> 1][(2 * m + 1) & 3];                        \
                 acc[0][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc0[0], acc[0][2 * m], 0, 0, 0);          \
-                acc[1][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc1[0], acc[1][2 * m], 0, 0, 0);          \
+                if constexpr (!QUARTER) acc[1][2 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc1[0], acc[1][2 * m], 0, 0, 0); \
                 acc[0][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc0[1], acc[0][2 * m + 1], 0, 0, 0);  \
-                acc[1][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc1[1], acc[1][2 * m + 1], 0, 0, 0);  \
+                if constexpr (!QUARTER) acc[1][2 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc1[1], acc[1][2 * m + 1], 0, 0, 0); \
                 APZ3_BODY_STAGING(k)                                                                               \
                 if ((m & 1) || m == 8) ur[m >> 1] = uload(2 * g + s + 1, m >> 1);                                  \
                 bc0 = bn0;                                                                                         \
@@ -440,8 +449,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         // Wave ph finishes board ph and sends its partial of board 1-ph.  No divergence: every wave runs the same
         // barriers; the missing second board of an odd batch's last pair is computed from a copy of the first and
         // never stored.
-        const int cot = 4 * h + ct;
-        const int bd_own = (ph == 0 || !two) ? bd0 : bd0 + 1;
+        const int cot = (QUARTER ? 2 : 4) * h + ct;
+        const int bd_own = ((QUARTER ? bsel == 0 : ph == 0) || !two) ? bd0 : bd0 + 1;
         // The epilogue's per-lane addresses are derived from an opaque copy of the lane id: computed from `lane` they
         // are loop invariants, hipcc keeps them in registers across the chunk loop (which has none to spare) and
         // spills them -- and every scratch reload is followed by vmcnt(0), a full drain of the loads and stores in flight.
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         const int s_lin = (le >> 2) * T::SROW + (le & 3) * 4;                   // plane piece `lane` (row lane>>2, quarter lane&3)
         const f32x4 bv = bload(r_bias, (unsigned)(eq * 16), (unsigned)(cot * 64));
         const unsigned ep_vo = le < 60 ? le * 16 : 0x80000000u;                 // piece `lane` of a plane; lanes 60..63 out of range
-        const unsigned st_out_vo = ((ph == 0) || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch: stores dropped
+        const unsigned st_out_vo = ((QUARTER ? bsel == 0 : ph == 0) || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch: stores dropped
         auto plane_so = [&](int r, int qp) {                                    // plane q' of step r
             return (unsigned)__builtin_amdgcn_readfirstlane(bd_own * T::C + cot * 16 + qp * 4 + r) * plane_b;
         };
@@ -491,9 +500,11 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         {
             constexpr int own = ph;             // static register indices
             f32x4 winb[2][4];                   // residual planes in flight: step r in winb[r & 1]
+            // QUARTER: sub-step r of a (tile, board) is finished by the row-half wave ph = (r >= 2); the other one only sends
+            auto finisher = [&](int r) { return !QUARTER || ((r >= 2) == (ph == 1)); };
             auto resid_load = [&](int r) {
 #pragma unroll
-                for (int qp = 0; qp < 4; qp++) winb[r & 1][qp] = bload(r_res, ep_vo, plane_so(r, qp));
+                for (int qp = 0; qp < 4; qp++) winb[r & 1][qp] = bload(r_res, finisher(r) ? ep_vo : 0x80000000u, plane_so(r, qp));
             };
             // X (one float per lane and value: [12][64]; any register can be stored, no packing moves)
             float* xs = xb + wave * T::XW + le;
@@ -568,10 +579,23 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 APZ3_STAMP(3)
 #pragma unroll
                 for (int qp = 0; qp < 4; qp++)
-                    bstore(r_out, st_out_vo, plane_so(r, qp), pv[qp]);
+                    bstore(r_out, finisher(r) ? st_out_vo : 0x80000000u, plane_so(r, qp), pv[qp]);
             };
 #if APZ3_EARLY_RESID
-            {
+            if constexpr (QUARTER) {
+                // one board per wave: its row partial is what it sends AND what it combines with the partner's
+                f32x2 q01[3][4], q23[3][4];
+                partial2(acc[0], std::integral_constant<int, 0>{}, q01);
+                if (RESID) {
+                    resid_load(0);
+                    resid_load(1);
+                }
+                step(0, 0, q01, q01);
+                step(1, 1, q01, q01);
+                partial2(acc[0], std::integral_constant<int, 2>{}, q23);
+                step(2, 0, q23, q23);
+                step(3, 1, q23, q23);
+            } else {
                 // Both partials of the OTHER board first: its 72 accumulators die, and the registers they free take the
                 // residual planes of steps 0 and 1 -- requested here, a transform pass ahead of their use, instead of
                 // inside step 0 where the epilogue then waited out their latency.
@@ -626,14 +650,21 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #endif
 }
 
-// Launch grid for n boards on `num_cu` CUs.  At least as many board pairs as CUs: one workgroup per CU (duo mode when
+// Launch grid for n boards on `num_cu` CUs (and, where the caller can launch the QUARTER variant, whether to).  At least as many board pairs as CUs: one workgroup per CU (duo mode when
 // num_cu is a multiple of 16, every workgroup takes >= 1 pair x one channel half).  Fewer pairs (training at the
 // reference's batch_size 128, small inference batches): TWO workgroups per pair -- the channel halves of a pair run on
 // two CUs at once instead of one after the other on one -- rounded up to whole groups of 16 blocks, which is what makes
 // the kernel pair blocks b and b + 8 up (duos beyond the last pair have no work and return).
-inline int wino3_grid(int n, int num_cu) {
+inline int wino3_grid(int n, int num_cu, bool* quarter = nullptr) {
     const int npairs = (n + 1) >> 1;
+    if (quarter) *quarter = false;
     if (npairs >= num_cu) return num_cu;
+    if (quarter && 4 * npairs <= num_cu) {      // at most a quarter of the CUs would get a pair: FOUR workgroups per pair
+        *quarter = true;                        // (QUARTER items of 32 output channels), whole groups of 32 blocks
+        const int g4 = (4 * npairs + 31) & ~31;
+        if (g4 <= num_cu) return g4;
+        *quarter = false;
+    }
     const int g = (2 * npairs + 15) & ~15;
     return g <= num_cu ? g : num_cu;
 }

@@ -264,6 +264,7 @@ int apz_set_trunk_arith(apz_engine *e, int arith);
 #define APZ_TRUNK_DIRECT 0
 #define APZ_TRUNK_WINOGRAD 3            /* default: batches of <= 32 boards take the small-batch form (csrc/trunk15_wino3s.h) */
 #define APZ_TRUNK_WINOGRAD_BATCHED 4    /* ... the batched form for every batch size (the tests hold the two forms to bit equality) */
+#define APZ_TRUNK_WINOGRAD_NO_QUARTER 5 /* ... the batched form with 64-channel work items only (no 32-channel items for few-pair batches) */
 int apz_test_select_trunk(apz_engine *e, int kind);
 int apz_kernel_time_ms(apz_engine *e, int kernel_class, float *out2);
 /* Enqueue `iters` forwards of n empty boards on the engine's stream and return without waiting (apz_sync waits).

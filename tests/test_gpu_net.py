@@ -492,12 +492,20 @@ def test_wino3_launch_shapes_do_not_change_a_boards_bits():
     net = PolicyValueNet(15, 15, batch_size=600, n_blocks=2, n_filter=128, model_params=prm)
     _, planes = random_positions(600, 15, seed=88)
     big = net.forward_with_logits(planes)                        # 300 pairs: one workgroup per CU
-    for lo, n in ((0, 1), (3, 2), (10, 17), (40, 130), (100, 300), (0, 512)):
+    # 33 ... 128 boards: QUARTER items (four workgroups per pair, 32 output channels each: csrc/trunk15_wino3.h)
+    for lo, n in ((0, 1), (3, 2), (10, 17), (50, 33), (7, 64), (60, 101), (300, 128), (40, 130), (100, 300), (0, 512)):
         small = net.forward_with_logits(planes[lo:lo + n])
         for a, b in zip(small, big):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b)[lo:lo + n], err_msg="n=%d" % n)
     o = net_ref.forward(prm, planes[:24], "resnet", 2, np.float64)
     np.testing.assert_allclose(big[0][:24], o[0], rtol=0, atol=LOGIT_ATOL)
+    # the quarter items against the float64 oracle directly, and against the 64-channel items forced onto the same batch
+    q = net.forward_with_logits(planes[300:364])
+    oq = net_ref.forward(prm, planes[300:364], "resnet", 2, np.float64)
+    np.testing.assert_allclose(q[0], oq[0], rtol=0, atol=LOGIT_ATOL)
+    net._ck(net.L.apz_test_select_trunk(net._h, 5))              # APZ_TRUNK_WINOGRAD_NO_QUARTER
+    for a, b in zip(net.forward_with_logits(planes[300:364]), q):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
     net.close()
 
 

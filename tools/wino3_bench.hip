@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "trunk15_wino3.h"
 
@@ -68,9 +69,11 @@ __global__ void wino_ref_kernel(const float* __restrict__ in, const float* __res
 int main(int argc, char** argv) {
     using T2 = apz::WinoPack;
     using T3 = apz::Wino3;
-    const char* tag = argc > 1 ? argv[1] : "wino3";
+    (void)argc; (void)argv;
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)(apz::trunk15_wino3_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)(apz::trunk15_wino3_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
     const int nmax = 4096;
     const size_t act = (size_t)nmax * 128 * 240;
     float *in, *res, *out, *out2, *upk, *bias;
@@ -230,21 +233,47 @@ int main(int argc, char** argv) {
             printf("check n=%5d resid=%d: max|wino3-naive| %.3e (max|ref| %.3f) nan %zu pad %zu  %s\n", n, resid, maxd, maxv, nan, pad_bad,
                    ok ? "ok" : "MISMATCH");
             if (!ok) bad++;
+            // QUARTER items (four workgroups per pair, 32 output channels each): the SAME bits, on the multiple-of-32 grid
+            // the launcher uses and on an odd grid (whole pairs per workgroup, quarter after quarter)
+            bool quarter = false;
+            const int gq = apz::wino3_grid(n, 256, &quarter);
+            for (int gi = 0; gi < (quarter ? 2 : 0); gi++) {
+                const int grid = gi == 0 ? gq : 7;
+                CK(hipMemset(out2, 0xff, cnt * 4));
+                if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true, true, true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+                else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false, true, true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(b.data(), out2, cnt * 4, hipMemcpyDeviceToHost));
+                size_t diff = 0;
+                for (size_t i = 0; i < cnt; i++)
+                    if ((i % 240) / 16 < 15 && memcmp(&a[i], &b[i], 4)) diff++;
+                printf("   quarter items n=%d resid=%d grid=%d: %zu values differ from the 64-channel items %s\n", n, resid, grid, diff, diff ? "MISMATCH" : "ok");
+                if (diff) bad++;
+            }
         }
     }
 
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const int sizes[4] = {128, 512, 1024, 4096};
+    const int sizes[7] = {32, 64, 128, 128, 512, 1024, 4096};
     for (int rep = 0; rep < (getenv("APZ_NO_TIMING") ? 0 : 2); rep++)
-    for (int si = 0; si < 4; si++) {
+    for (int si = 0; si < 7; si++) {
         const int n = sizes[si];
-        const int grid3 = apz::wino3_grid(n, 256);
+        bool quarter = false;
+        const int gq = apz::wino3_grid(n, 256, &quarter);
+        const bool useq = quarter && si != 3;                 // 128 boards twice: quarter items, then the 64-channel items
+        const int grid3 = useq ? gq : apz::wino3_grid(n, 256);
+        const char* tag = useq ? "quarter" : "half";
         for (int kern = 1; kern < 2; kern++)
         for (int resid = 0; resid < 2; resid++) {
             auto launch = [&]() {
-                if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
-                else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                if (useq) {
+                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true, true, true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                    else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false, true, true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                } else {
+                    if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                    else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid3), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out, n);
+                }
             };
             for (int i = 0; i < 5; i++) launch();
             CK(hipEventRecord(a, 0));
