@@ -121,7 +121,8 @@ struct apz_engine {
     uint64_t* smp_keys = nullptr;
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
-    double* bn_sums = nullptr;                     // apz_bn_fwd / _bwd: per-channel reduction scratch
+    double* bn_part = nullptr;                     // apz_bn_fwd / _bwd: per-(channel, batch split) partial sums [256 * BN_SPLITS][2]
+    unsigned* tail_counters = nullptr;             // apz_bias_grad: grid_tail tickets per channel (conv_train.h), zero between launches
     float* wgw_scratch = nullptr;                  // apz_wgrad_wino: partial dU per batch slice
     double* fold_ws = nullptr;                     // apz_load_weights_dev: scale / shift of one layer (2 x 256 doubles)
     float* head_scratch = nullptr;                 // apz_conv1x1_bwd / apz_pv_loss: per-board partial sums
@@ -680,7 +681,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_sums, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws,
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_part, e->tail_counters, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws,
                    e->wfc_raw, e->w3s_slabs, e->w3s_tickets};
     for (void* p : dev)
         if (p) hipFree(p);
@@ -1148,7 +1149,7 @@ struct StreamScope {      // run the engine's launch helpers on a caller-supplie
     hipStream_t saved;
     StreamScope(apz_engine* e_, void* s) : e(e_), saved(e_->stream) {
         if (s != APZ_ENGINE_STREAM) e->stream = (hipStream_t)s;   // NULL is a valid handle: the null stream
-        // The training entry points share per-engine scratch (head_scratch, bn_sums, fold_ws, wgw_scratch, wino_scratch,
+        // The training entry points share per-engine scratch (head_scratch, bn_part, fold_ws, wgw_scratch, wino_scratch,
         // adam_tab).  Calls on ONE stream are ordered by the stream; a caller that switches streams gets the new stream
         // ordered behind everything queued on the previous one, so two streams never work on the scratch at once.
         if (e->scratch_stream_valid && e->scratch_stream != e->stream) {
@@ -1326,6 +1327,17 @@ int apz_wino_pack(apz_engine* e, const void* w_dev, int transpose_flip, void* up
     return APZ_OK;
 }
 
+int apz_wino_pack_many(apz_engine* e, const void* w_dev, int count, void* upk_dev, void* stream) {
+    if (!e || !w_dev || !upk_dev || count < 1 || count > 16384) return fail(APZ_E_ARG, "bad argument");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    hipLaunchKernelGGL(apz::pack_wino2_many_kernel, dim3(8 * 2 * 32 * 64 / 256, 2 * count), dim3(256), 0, e->stream,
+                       (const float*)w_dev, (float*)upk_dev);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int apz_wino_conv_add(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, const void* resid_dev,
                       void* y_dev, int n, int relu, int layout, void* stream) {
     if (!e || !x_dev || !upk_dev || !y_dev || n < 1 || layout < 0 || layout > 1) return fail(APZ_E_ARG, "bad argument");
@@ -1438,10 +1450,15 @@ int bn_geometry(apz_engine* e, int layout, int* ps, int* rs) {
     }
     return APZ_OK;
 }
-int bn_sums(apz_engine* e) {   // [256][2] doubles, zeroed on the caller's stream
-    if (!e->bn_sums) HIP_TRY(hipMalloc((void**)&e->bn_sums, 256 * 2 * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(e->bn_sums, 0, 256 * 2 * sizeof(double), e->stream));
+constexpr int BN_SPLITS = 64;      // batch splits per channel at most (every consumer workgroup adds them)
+int bn_scratch(apz_engine* e) {    // per-(channel, split) partial sums: overwritten by every statistics launch, nothing to zero
+    if (!e->bn_part) HIP_TRY(hipMalloc((void**)&e->bn_part, (size_t)256 * BN_SPLITS * 2 * sizeof(double)));
     return APZ_OK;
+}
+// grid.y of the four BatchNorm launches: channels x splits ~ 8 workgroups per CU (padded rows: four boards per trip)
+int bn_splits(const apz_engine* e, int n, int C, int layout) {
+    const int per = layout == APZ_LAYOUT_ROWS16 ? (n + 3) / 4 : n;
+    return std::max(1, std::min({per, (e->num_cu * (layout == APZ_LAYOUT_ROWS16 ? 8 : 4)) / C, BN_SPLITS}));
 }
 }  // namespace
 
@@ -1455,66 +1472,75 @@ int apz_bn_fwd(apz_engine* e, const void* x_dev, const void* resid_dev, const vo
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    if (int rc = bn_sums(e)) return rc;
+    if (int rc = bn_scratch(e)) return rc;
     const int H = e->cfg.height, W = e->cfg.width;
-    const int splits = std::max(1, std::min(n, (e->num_cu * 4) / C));
-    const bool r16 = layout == APZ_LAYOUT_ROWS16;
-    if (r16)
-        hipLaunchKernelGGL(apz::bn_stats_r16_kernel, dim3(C, std::max(1, std::min((n + 3) / 4, (e->num_cu * 8) / C))), dim3(256),
-                           0, e->stream, (const float*)x_dev, e->bn_sums, n, C);
-    else
-        hipLaunchKernelGGL(apz::bn_stats_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_sums, n, C,
+    const int splits = bn_splits(e, n, C, layout);
+    const apz::BnFinal fin{(float*)mean_dev, (float*)invstd_dev, (float*)run_mean_dev, (float*)run_var_dev, (double)n * H * W, eps,
+                           momentum};
+    if (layout == APZ_LAYOUT_ROWS16) {
+        hipLaunchKernelGGL(apz::bn_stats_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_part, n, C);
+        hipLaunchKernelGGL(apz::bn_apply_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev,
+                           (const float*)resid_dev, (const float*)gamma_dev, (const float*)beta_dev, (const double*)e->bn_part,
+                           splits, fin, (float*)y_dev, n, C, relu);
+    } else {
+        hipLaunchKernelGGL(apz::bn_stats_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_part, n, C,
                            ps, rs, H, W);
-    hipLaunchKernelGGL(apz::bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, e->stream, e->bn_sums, (float*)mean_dev,
-                       (float*)invstd_dev, (float*)run_mean_dev, (float*)run_var_dev, C, (double)n * H * W, eps, momentum);
-    const long planes = (long)n * C;
-    const int grid = (int)std::min<long>((planes * ps + 255) / 256, 16384);
-    if (r16)
-        hipLaunchKernelGGL(apz::bn_apply_r16_kernel, dim3((int)std::min<long>((planes * 60 + 255) / 256, 16384)), dim3(256), 0,
-                           e->stream, (const float*)x_dev, (const float*)resid_dev, (const float*)gamma_dev,
-                           (const float*)beta_dev, (const float*)mean_dev, (const float*)invstd_dev, (float*)y_dev, planes, C,
-                           relu);
-    else
-        hipLaunchKernelGGL(apz::bn_apply_kernel, dim3(grid), dim3(256), 0, e->stream, (const float*)x_dev,
-                           (const float*)resid_dev, (const float*)gamma_dev, (const float*)beta_dev, (const float*)mean_dev,
-                           (const float*)invstd_dev, (float*)y_dev, planes, C, ps, rs, W, relu);
+        hipLaunchKernelGGL(apz::bn_apply_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev,
+                           (const float*)resid_dev, (const float*)gamma_dev, (const float*)beta_dev, (const double*)e->bn_part,
+                           splits, fin, (float*)y_dev, n, C, ps, rs, H, W, relu);
+    }
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
 
+int apz_bn_bwd_splits(apz_engine* e, int n, int C, int layout) {
+    if (!e || n < 1 || C < 1 || C > 256 || layout < 0 || layout > 1) return fail(APZ_E_ARG, "bad argument");
+    return bn_splits(e, n, C, layout);
+}
+
 int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void* out_dev, const void* gamma_dev,
                const void* mean_dev, const void* invstd_dev, void* dx_dev, void* dres_dev, void* dgamma_dev, void* dbeta_dev,
-               int n, int C, int layout, int relu, void* stream) {
-    if (!e || !dy_dev || !x_dev || !mean_dev || !invstd_dev || !dx_dev || n < 1 || C < 1 || C > 256 || (relu && !out_dev))
+               void* dxsum_dev, int dxsum_ld, int n, int C, int layout, int relu, void* stream) {
+    if (!e || !dy_dev || !x_dev || !mean_dev || !invstd_dev || !dx_dev || n < 1 || C < 1 || C > 256 || (relu && !out_dev) ||
+        (dxsum_dev && dxsum_ld < C))
         return fail(APZ_E_ARG, "bad argument");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    if (int rc = bn_sums(e)) return rc;
+    if (int rc = bn_scratch(e)) return rc;
     const int H = e->cfg.height, W = e->cfg.width;
-    const int splits = std::max(1, std::min(n, (e->num_cu * 4) / C));
-    const long planes = (long)n * C;
-    const int grid = (int)std::min<long>((planes * ps + 255) / 256, 16384);
+    const int splits = bn_splits(e, n, C, layout);
     if (layout == APZ_LAYOUT_ROWS16) {
-        hipLaunchKernelGGL(apz::bn_bwd_reduce_r16_kernel, dim3(C, std::max(1, std::min((n + 3) / 4, (e->num_cu * 8) / C))),
-                           dim3(256), 0, e->stream, (const float*)dy_dev, (const float*)x_dev, (const float*)out_dev,
-                           (const float*)mean_dev, (const float*)invstd_dev, e->bn_sums, n, C, relu);
-        hipLaunchKernelGGL(apz::bn_bwd_apply_r16_kernel, dim3((int)std::min<long>((planes * 60 + 255) / 256, 16384)), dim3(256),
-                           0, e->stream, (const float*)dy_dev, (const float*)x_dev, (const float*)out_dev,
-                           (const float*)gamma_dev, (const float*)mean_dev, (const float*)invstd_dev, (const double*)e->bn_sums,
-                           (float*)dx_dev, (float*)dres_dev, (float*)dgamma_dev, (float*)dbeta_dev, planes, C, relu,
-                           (double)n * H * W);
+        hipLaunchKernelGGL(apz::bn_bwd_reduce_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
+                           (const float*)x_dev, (const float*)out_dev, (const float*)mean_dev, (const float*)invstd_dev,
+                           e->bn_part, n, C, relu);
+        hipLaunchKernelGGL(apz::bn_bwd_apply_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
+                           (const float*)x_dev, (const float*)out_dev, (const float*)gamma_dev, (const float*)mean_dev,
+                           (const float*)invstd_dev, (const double*)e->bn_part, splits, (float*)dx_dev, (float*)dres_dev,
+                           (float*)dgamma_dev, (float*)dbeta_dev, (float*)dxsum_dev, dxsum_ld, n, C, relu, (double)n * H * W);
     } else {
         hipLaunchKernelGGL(apz::bn_bwd_reduce_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
                            (const float*)x_dev, (const float*)out_dev, (const float*)mean_dev, (const float*)invstd_dev,
-                           e->bn_sums, n, C, ps, rs, H, W, relu);
-        hipLaunchKernelGGL(apz::bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, e->stream, (const float*)dy_dev,
+                           e->bn_part, n, C, ps, rs, H, W, relu);
+        hipLaunchKernelGGL(apz::bn_bwd_apply_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
                            (const float*)x_dev, (const float*)out_dev, (const float*)gamma_dev, (const float*)mean_dev,
-                           (const float*)invstd_dev, (const double*)e->bn_sums, (float*)dx_dev, (float*)dres_dev,
-                           (float*)dgamma_dev, (float*)dbeta_dev, planes, C, ps, rs, W, relu, (double)n * H * W);
+                           (const float*)invstd_dev, (const double*)e->bn_part, splits, (float*)dx_dev, (float*)dres_dev,
+                           (float*)dgamma_dev, (float*)dbeta_dev, (float*)dxsum_dev, dxsum_ld, n, C, ps, rs, H, W, relu,
+                           (double)n * H * W);
     }
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
+int apz_colsum(apz_engine* e, const void* in_dev, void* out_dev, int rows, int cols, float scale, void* stream) {
+    if (!e || !in_dev || !out_dev || rows < 1 || cols < 1) return fail(APZ_E_ARG, "bad argument");
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    StreamScope sc(e, stream);
+    hipLaunchKernelGGL(apz::colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, e->stream, (const float*)in_dev, (float*)out_dev,
+                       rows, cols, scale);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -1546,10 +1572,8 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     }
     hipLaunchKernelGGL(apz::wgrad_wino2_kernel, dim3(T2::BLOCKS * slices), dim3(T2::THREADS), T2::LDS_BYTES, e->stream,
                        (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
-    hipLaunchKernelGGL(apz::wgrad_wino_sum_kernel, dim3(36 * 128 * 128 / 4 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
-                       slices);
-    hipLaunchKernelGGL(apz::wgrad_wino_reduce_kernel, dim3(128 * 128 / 256), dim3(256), 0, e->stream, e->wgw_scratch,
-                       (float*)dw_dev);
+    hipLaunchKernelGGL(apz::wgrad_wino_finish_kernel, dim3(128 * 128 / 64), dim3(256), 0, e->stream,
+                       (const float*)e->wgw_scratch, slices, (float*)dw_dev);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -1611,7 +1635,8 @@ int apz_conv1x1_fwd(apz_engine* e, const void* x_dev, const void* w_dev, const v
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    hipLaunchKernelGGL(apz::conv1x1_fwd_kernel, dim3(n), dim3(256), (size_t)CO * C * sizeof(float), e->stream,
+    hipLaunchKernelGGL(apz::conv1x1_fwd_kernel, dim3(n, (e->cfg.height * e->cfg.width + 63) / 64), dim3(256),
+                       ((size_t)CO * C + 4 * 8 * 64) * sizeof(float), e->stream,
                        (const float*)x_dev, (const float*)w_dev, (const float*)bias_dev, (float*)y_dev, C, CO, e->cfg.height,
                        e->cfg.width, ps, rs);
     HIP_TRY(hipGetLastError());
@@ -1629,8 +1654,8 @@ int apz_conv1x1_bwd(apz_engine* e, const void* x_dev, const void* w_dev, const v
     StreamScope sc(e, stream);
     const int P = e->cfg.height * e->cfg.width;
     if (int rc = head_scratch(e, (size_t)n * CO * C)) return rc;
-    const size_t lds = ((size_t)CO * C + (size_t)CO * P + 8 * 128) * sizeof(float);
-    hipLaunchKernelGGL(apz::conv1x1_bwd_kernel, dim3(n), dim3(256), lds, e->stream, (const float*)x_dev, (const float*)w_dev,
+    const size_t lds = ((size_t)CO * 32 + (size_t)CO * P) * sizeof(float);
+    hipLaunchKernelGGL(apz::conv1x1_bwd_kernel, dim3(n, (C + 31) / 32), dim3(256), lds, e->stream, (const float*)x_dev, (const float*)w_dev,
                        (const float*)dy_dev, (float*)dx_dev, e->head_scratch, C, CO, e->cfg.height, e->cfg.width, ps, rs,
                        accumulate_dx);
     hipLaunchKernelGGL(apz::colsum_kernel, dim3((CO * C + 63) / 64), dim3(256), 0, e->stream, (const float*)e->head_scratch,
@@ -1641,7 +1666,7 @@ int apz_conv1x1_bwd(apz_engine* e, const void* x_dev, const void* w_dev, const v
 }
 
 int apz_bias_grad(apz_engine* e, const void* dy_dev, void* db_dev, int n, int C, int layout, void* stream) {
-    if (!e || !dy_dev || !db_dev || n < 1 || C < 1) return fail(APZ_E_ARG, "bad argument");
+    if (!e || !dy_dev || !db_dev || n < 1 || C < 1 || C > 256) return fail(APZ_E_ARG, "bad argument");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
     EngineLock guard(e->submit_lock);
@@ -1649,10 +1674,12 @@ int apz_bias_grad(apz_engine* e, const void* dy_dev, void* db_dev, int n, int C,
     StreamScope sc(e, stream);
     const int slices = std::max(1, std::min(n, (e->num_cu * 8 + C - 1) / C));
     if (int rc = head_scratch(e, (size_t)slices * C)) return rc;
-    hipLaunchKernelGGL(apz::bias_grad_kernel, dim3(C, slices), dim3(256), 0, e->stream, (const float*)dy_dev, e->head_scratch, n, C,
-                       ps);
-    hipLaunchKernelGGL(apz::colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, e->stream, (const float*)e->head_scratch,
-                       (float*)db_dev, slices, C, 1.0f);
+    if (!e->tail_counters) {
+        HIP_TRY(hipMalloc((void**)&e->tail_counters, 256 * sizeof(unsigned)));
+        HIP_TRY(hipMemset(e->tail_counters, 0, 256 * sizeof(unsigned)));
+    }
+    hipLaunchKernelGGL(apz::bias_grad_kernel, dim3(C, slices), dim3(256), 0, e->stream, (const float*)dy_dev, e->head_scratch,
+                       (float*)db_dev, e->tail_counters, n, C, ps);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }

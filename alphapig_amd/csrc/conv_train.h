@@ -55,9 +55,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 // w [128][128][3][3] -> the transformed weights of trunk15_wino3_kernel, U = G g G^T in fp32:
 // [cot 8][row half 2][c4 32][lane 64][20] (wino_common.h).  One thread per (cot, pass, c4, lane): 18 values,
 // 80 contiguous bytes.  transpose_flip: the weights of the data-gradient convolution (see above).
-__global__ void pack_wino2_kernel(const float* __restrict__ w, float* __restrict__ upk, int transpose_flip) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 8 * 2 * 32 * 64) return;
+__device__ __forceinline__ void pack_wino2_thread(const float* __restrict__ w, float* __restrict__ upk, int transpose_flip, int i) {
     const int lane = i & 63, c4 = (i >> 6) & 31, pass = (i >> 11) & 1, cot = i >> 12;
     const int co = cot * 16 + (lane & 15), ci = c4 * 4 + (lane >> 4);
     float g[3][3];
@@ -97,6 +95,19 @@ __global__ void pack_wino2_kernel(const float* __restrict__ w, float* __restrict
 #pragma unroll
     for (int v = 0; v < 5; v++) dst[v] = f32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
 }
+__global__ void pack_wino2_kernel(const float* __restrict__ w, float* __restrict__ upk, int transpose_flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 8 * 2 * 32 * 64) pack_wino2_thread(w, upk, transpose_flip, i);
+}
+// `count` layers whose weights sit back to back ([count][128][128][3][3]), both orientations, in one launch (grid.y = 2 count):
+// upk [count][2][UPK_FLOATS] (forward, then data gradient) -- a training step packs its 20 trunk layers twice, and 40
+// launches of 5 us were 4 % of the step at the reference's batch size
+__global__ void pack_wino2_many_kernel(const float* __restrict__ w, float* __restrict__ upk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int layer = blockIdx.y >> 1, flip = blockIdx.y & 1;
+    if (i < 8 * 2 * 32 * 64)
+        pack_wino2_thread(w + (size_t)layer * (128 * 128 * 9), upk + (size_t)blockIdx.y * (8 * 2 * 32 * 64 * 20), flip, i);
+}
 
 // dense [planes][15][15] <-> rows16 [planes][15][16] (pad column written as zero)
 __global__ void rows16_from_dense_kernel(const float* __restrict__ x, float* __restrict__ y, long planes) {
@@ -116,15 +127,62 @@ __global__ void rows16_to_dense_kernel(const float* __restrict__ x, float* __res
     }
 }
 
+// ---- the workgroup that draws a channel's LAST ticket finishes the channel's reduction (bias_grad_kernel,
+// heads_train.h: grid (channel, batch slice)): thread 0 of every workgroup writes its partial result with tail_store (a
+// write-through store: device-scope, visible to the other XCDs once acknowledged), waits for the acknowledgement and
+// takes a ticket from the CHANNEL's counter; the workgroup that gets the channel's last ticket reads the channel's
+// partials with tail_load (device-scope loads: past its own L1 / L2) and adds them in a fixed order.  Measured on the
+// way (profiles/r04_train_fusion.md): a device-scope release fence (`__threadfence()`) per workgroup writes back the
+// XCD's whole L2 -- 2 048 workgroups per launch took the training step from 5.0 to 15.4 ms; ONE ticket counter per
+// launch serialises 2 048 atomics on one address (+25 us per launch); and even per-channel tickets put ~5 us of
+// dependent device-scope round trips (store, acknowledge, atomic, loads) at the end of the kernel -- as much as the
+// second launch they replace.  Hence the BatchNorm kernels below do NOT use tickets: their consumers add the partials.
+// The last workgroup puts its counter back to 0: launches that share counters must be ordered by their stream.
+template <typename T>
+__device__ __forceinline__ void tail_store(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T tail_load(const T* p) {
+    return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all threads of the workgroup call; thread 0 must be the one that made the workgroup's tail_store()s
+__device__ __forceinline__ bool grid_tail(unsigned* counter, unsigned total) {
+    __shared__ unsigned tk;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the partials have arrived before the ticket is taken
+        tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == total - 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return tk == total - 1;
+}
+
 // ---- training-mode BatchNorm (+ residual, + ReLU) over [n][C][H][W] planes with plane stride PS and row
 // stride RS (dense NCHW: PS = H*W, RS = W; the trunk's padded-row layout: PS = 240, RS = 16).  Statistics are
 // over the n*H*W valid elements of a channel; pad columns (x >= W) are written as zero and never read.
-//   bn_stats_kernel      sums[c] += (sum x, sum x^2) in double (atomics; zeroed by the launcher); grid (C, splits)
-//   bn_finalize_kernel   mean, 1/sqrt(var + eps) per channel; moving statistics (torch semantics: unbiased
-//                        variance in the moving average, momentum = weight of the NEW value)
-//   bn_apply_kernel      y = act((x - mean) * invstd * gamma + beta (+ resid))
-//   bn_bwd_reduce_kernel sums[c] += (sum dz, sum dz * xhat), dz = dy (* [out > 0] with ReLU)
-//   bn_bwd_apply_kernel  dx = gamma * invstd * (dz - s1/M - xhat * s2/M); dres = dz
+// Two launches forward, two backward, every one a grid (channel, batch split); nothing is zeroed beforehand and there
+// are no atomics (round 3: memset + statistics with double atomics + finalize + apply -- each small launch ~5 us of
+// queue time; and the sums depended on the arrival order in their last bits):
+//   bn_stats_kernel      part[c][split] = (sum x, sum x^2) in double, plain stores
+//   bn_apply_kernel      every workgroup adds ITS channel's partials (<= 64 pairs of doubles, a fixed order) and derives
+//                        mean, 1/sqrt(var + eps); y = act((x - mean) * invstd * gamma + beta (+ resid)); workgroup
+//                        (c, 0) writes mean / invstd for the backward pass and the moving statistics (torch semantics:
+//                        unbiased variance in the moving average, momentum = weight of the NEW value)
+//   bn_bwd_reduce_kernel part[c][split] = (sum dz, sum dz * xhat), dz = dy (* [out > 0] with ReLU)
+//   bn_bwd_apply_kernel  adds its channel's partials: s1, s2; dx = gamma * invstd * (dz - s1/M - xhat * s2/M); dres = dz;
+//                        workgroup (c, 0) writes dbeta = s1, dgamma = s2; dxsum (may be NULL): row `split` of
+//                        [splits][ld] floats gets the sum of the dx this workgroup wrote -- the bias gradient of the
+//                        convolution in front of the BatchNorm is the column sum of that matrix (colsum_kernel,
+//                        heads_train.h; the trainer adds all layers' rows in ONE launch)
+struct BnFinal {            // what workgroup (c, 0) of bn_apply writes (run_* may be NULL)
+    float* mean;
+    float* invstd;
+    float* run_mean;
+    float* run_var;
+    double M;               // elements per channel
+    float eps, momentum;
+};
 __device__ __forceinline__ double block_sum_256(double v, double* sh) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -134,8 +192,38 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     __syncthreads();
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
+// the two sums of channel c over its `splits` partials, to every thread: thread k loads split k (k + 256, ...), then
+// the shuffle tree -- a fixed order
+__device__ __forceinline__ void channel_sums(const double* __restrict__ part, int c, int splits, double* sh, double& s1,
+                                             double& s2) {
+    s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < splits; k += 256) {
+        s1 += part[2 * ((size_t)c * splits + k)];
+        s2 += part[2 * ((size_t)c * splits + k) + 1];
+    }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+}
+// ... turned into the channel's mean and 1 / sqrt(var + eps); workgroup (c, 0) records them
+__device__ __forceinline__ void channel_stats(const double* __restrict__ part, int c, int splits, double* sh, const BnFinal& f,
+                                              float& mean, float& invstd) {
+    double s1, s2;
+    channel_sums(part, c, splits, sh, s1, s2);
+    const double m = s1 / f.M;
+    double var = s2 / f.M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        f.mean[c] = mean;
+        f.invstd[c] = invstd;
+        if (f.run_mean) f.run_mean[c] = f.run_mean[c] * (1.f - f.momentum) + f.momentum * (float)m;
+        if (f.run_var)
+            f.run_var[c] = f.run_var[c] * (1.f - f.momentum) + f.momentum * (float)(f.M > 1.0 ? var * f.M / (f.M - 1.0) : var);
+    }
+}
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int n, int C,
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int n, int C,
                                                        int PS, int RS, int H, int W) {
     __shared__ double sh[4];
     const int c = blockIdx.x, HW = H * W;
@@ -152,49 +240,39 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     s1 = block_sum_256(s1, sh);
     s2 = block_sum_256(s2, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * c], s1);
-        atomicAdd(&sums[2 * c + 1], s2);
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y)] = s1;
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y) + 1] = s2;
     }
-}
-
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ run_mean, float* __restrict__ run_var, int C, double M, float eps,
-                                   float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double m = sums[2 * c] / M;
-    double var = sums[2 * c + 1] / M - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (run_mean) run_mean[c] = run_mean[c] * (1.f - momentum) + momentum * (float)m;
-    if (run_var) run_var[c] = run_var[c] * (1.f - momentum) + momentum * (float)(M > 1.0 ? var * M / (M - 1.0) : var);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       float* __restrict__ y, long planes, int C, int PS, int RS, int W,
+                                                       const double* __restrict__ part, int psplits, BnFinal fin,
+                                                       float* __restrict__ y, int n, int C, int PS, int RS, int H, int W,
                                                        int relu) {
-    const long total = planes * PS;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pl = i / PS;
-        const int rem = (int)(i - pl * PS), col = rem % RS, c = (int)(pl % C);
-        float v = 0.f;
-        if (col < W) {
-            const float g = gamma ? gamma[c] : 1.f;
-            v = (x[i] - mean[c]) * invstd[c] * g + beta[c];
-            if (resid) v += resid[i];
-            if (relu) v = fmaxf(v, 0.f);
+    __shared__ double sh[4];
+    const int c = blockIdx.x, cells = H * RS;
+    float m, is;
+    channel_stats(part, c, psplits, sh, fin, m, is);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta[c];
+    for (int b = blockIdx.y; b < n; b += gridDim.y) {
+        const size_t base = ((size_t)b * C + c) * PS;
+        for (int q = threadIdx.x; q < cells; q += 256) {
+            float v = 0.f;
+            if (q % RS < W) {
+                v = (x[base + q] - m) * is * g + bt;
+                if (resid) v += resid[base + q];
+                if (relu) v = fmaxf(v, 0.f);
+            }
+            y[base + q] = v;
         }
-        y[i] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ out, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, double* __restrict__ sums,
-                                                            int n, int C, int PS, int RS, int H, int W, int relu) {
+                                                            const float* __restrict__ invstd, double* __restrict__ part, int n,
+                                                            int C, int PS, int RS, int H, int W, int relu) {
     __shared__ double sh[4];
     const int c = blockIdx.x, HW = H * W;
     const float m = mean[c], is = invstd[c];
@@ -213,39 +291,48 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     s1 = block_sum_256(s1, sh);
     s2 = block_sum_256(s2, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * c], s1);
-        atomicAdd(&sums[2 * c + 1], s2);
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y)] = s1;
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y) + 1] = s2;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ out, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const double* __restrict__ sums, float* __restrict__ dx,
+                                                           const double* __restrict__ part, int psplits, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, long planes, int C, int PS, int RS,
-                                                           int W, int relu, double M) {
-    const long total = planes * PS;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pl = i / PS;
-        const int rem = (int)(i - pl * PS), col = rem % RS, c = (int)(pl % C);
-        float gx = 0.f, gr = 0.f;
-        if (col < W) {
-            float dz = dy[i];
-            if (relu && !(out[i] > 0.f)) dz = 0.f;
-            const float xhat = (x[i] - mean[c]) * invstd[c];
-            const float g = gamma ? gamma[c] : 1.f;
-            gx = g * invstd[c] * (dz - (float)(sums[2 * c] / M) - xhat * (float)(sums[2 * c + 1] / M));
-            gr = dz;
-        }
-        dx[i] = gx;
-        if (dres) dres[i] = gr;
+                                                           float* __restrict__ dbeta, float* __restrict__ dxsum, int dxsum_ld,
+                                                           int n, int C, int PS, int RS, int H, int W, int relu, double M) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, cells = H * RS;
+    double s1, s2;
+    channel_sums(part, c, psplits, sh, s1, s2);
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
     }
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dbeta) dbeta[c] = (float)sums[2 * c];
-            if (dgamma) dgamma[c] = (float)sums[2 * c + 1];
+    const float k0 = (float)(s1 / M), k1 = (float)(s2 / M), m = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.f;
+    double ds = 0.0;
+    for (int b = blockIdx.y; b < n; b += gridDim.y) {
+        const size_t base = ((size_t)b * C + c) * PS;
+        for (int q = threadIdx.x; q < cells; q += 256) {
+            float gx = 0.f, gr = 0.f;
+            if (q % RS < W) {
+                float dz = dy[base + q];
+                if (relu && !(out[base + q] > 0.f)) dz = 0.f;
+                const float xhat = (x[base + q] - m) * is;
+                gx = g * is * (dz - k0 - xhat * k1);
+                gr = dz;
+            }
+            dx[base + q] = gx;
+            if (dres) dres[base + q] = gr;
+            ds += gx;
         }
+    }
+    if (dxsum) {
+        ds = block_sum_256(ds, sh);
+        if (threadIdx.x == 0) dxsum[(size_t)blockIdx.y * dxsum_ld + c] = (float)ds;
+    }
 }
 
 // ---- Adam as Module.init_optimizer configures it in the reference (policy_value_net_mxnet.py:198-205): ONE launch over
@@ -275,8 +362,9 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamTensor* __rest
 }
 
 // ---- the same four kernels for the padded-row layout (plane = 60 float4; pad elements are zero on input, so
-// they add nothing to any sum, and are written back as zero): 16-byte accesses, no per-element index division
-__global__ __launch_bounds__(256) void bn_stats_r16_kernel(const float* __restrict__ x, double* __restrict__ sums, int n, int C) {
+// they add nothing to any sum, and are written back as zero): 16-byte accesses, no per-element index division;
+// a workgroup walks four boards per trip (4 x 60 of its 256 threads)
+__global__ __launch_bounds__(256) void bn_stats_r16_kernel(const float* __restrict__ x, double* __restrict__ part, int n, int C) {
     __shared__ double sh[4];
     const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;   // 4 boards per trip, 60 float4 each
     double s1 = 0.0, s2 = 0.0;
@@ -289,35 +377,38 @@ __global__ __launch_bounds__(256) void bn_stats_r16_kernel(const float* __restri
     s1 = block_sum_256(s1, sh);
     s2 = block_sum_256(s2, sh);
     if (t == 0) {
-        atomicAdd(&sums[2 * c], s1);
-        atomicAdd(&sums[2 * c + 1], s2);
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y)] = s1;
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y) + 1] = s2;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_apply_r16_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           float* __restrict__ y, long planes, int C, int relu) {
-    const long total = planes * 60;
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
-        const long pl = v / 60;
-        const int c = (int)(pl % C);
-        const float sc = invstd[c] * (gamma ? gamma[c] : 1.f), sh = beta[c] - mean[c] * sc;
-        f32x4 a = reinterpret_cast<const f32x4*>(x)[v];
-        a = a * sc + sh;
-        if (resid) a += reinterpret_cast<const f32x4*>(resid)[v];
+                                                           const double* __restrict__ part, int psplits, BnFinal fin,
+                                                           float* __restrict__ y, int n, int C, int relu) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;
+    float m, is;
+    channel_stats(part, c, psplits, sh, fin, m, is);
+    const float sc = is * (gamma ? gamma[c] : 1.f), shf = beta[c] - m * sc;
+    if (sub >= 4) return;
+    for (int b = blockIdx.y * 4 + sub; b < n; b += gridDim.y * 4) {
+        const size_t o = ((size_t)b * C + c) * 60 + k;
+        f32x4 a = reinterpret_cast<const f32x4*>(x)[o];
+        a = a * sc + shf;
+        if (resid) a += reinterpret_cast<const f32x4*>(resid)[o];
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; e++) a[e] = fmaxf(a[e], 0.f);
         }
-        if ((v & 3) == 3) a[3] = 0.f;            // the pad column (60 float4 per plane: 4 per row)
-        reinterpret_cast<f32x4*>(y)[v] = a;
+        if ((k & 3) == 3) a[3] = 0.f;            // the pad column (60 float4 per plane: 4 per row)
+        reinterpret_cast<f32x4*>(y)[o] = a;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_r16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ out, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, double* __restrict__ sums,
+                                                                const float* __restrict__ invstd, double* __restrict__ part,
                                                                 int n, int C, int relu) {
     __shared__ double sh[4];
     const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;
@@ -345,42 +436,52 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_r16_kernel(const float* __r
     s1 = block_sum_256(s1, sh);
     s2 = block_sum_256(s2, sh);
     if (t == 0) {
-        atomicAdd(&sums[2 * c], s1);
-        atomicAdd(&sums[2 * c + 1], s2);
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y)] = s1;
+        part[2 * ((size_t)c * gridDim.y + blockIdx.y) + 1] = s2;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_r16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ out, const float* __restrict__ gamma,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                               const double* __restrict__ sums, float* __restrict__ dx,
-                                                               float* __restrict__ dres, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, long planes, int C, int relu, double M) {
-    const long total = planes * 60;
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
-        const long pl = v / 60;
-        const int c = (int)(pl % C);
-        const float m = mean[c], is = invstd[c], k0 = (float)(sums[2 * c] / M), k1 = (float)(sums[2 * c + 1] / M);
-        const float gi = (gamma ? gamma[c] : 1.f) * is;
-        f32x4 g = reinterpret_cast<const f32x4*>(dy)[v];
-        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[v];
-        if (relu) {
-            const f32x4 ov = reinterpret_cast<const f32x4*>(out)[v];
-#pragma unroll
-            for (int e = 0; e < 4; e++) g[e] = ov[e] > 0.f ? g[e] : 0.f;
-        }
-        f32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; e++) r[e] = gi * (g[e] - k0 - (xv[e] - m) * is * k1);
-        if ((v & 3) == 3) r[3] = 0.f, g[3] = 0.f;
-        reinterpret_cast<f32x4*>(dx)[v] = r;
-        if (dres) reinterpret_cast<f32x4*>(dres)[v] = g;
+                                                               const double* __restrict__ part, int psplits,
+                                                               float* __restrict__ dx, float* __restrict__ dres,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dxsum, int dxsum_ld, int n, int C, int relu,
+                                                               double M) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;
+    double s1, s2;
+    channel_sums(part, c, psplits, sh, s1, s2);
+    if (blockIdx.y == 0 && t == 0) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
     }
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dbeta) dbeta[c] = (float)sums[2 * c];
-            if (dgamma) dgamma[c] = (float)sums[2 * c + 1];
+    const float m = mean[c], is = invstd[c], k0 = (float)(s1 / M), k1 = (float)(s2 / M);
+    const float gi = (gamma ? gamma[c] : 1.f) * is;
+    double ds = 0.0;
+    if (sub < 4)
+        for (int b = blockIdx.y * 4 + sub; b < n; b += gridDim.y * 4) {
+            const size_t o = ((size_t)b * C + c) * 60 + k;
+            f32x4 g = reinterpret_cast<const f32x4*>(dy)[o];
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x)[o];
+            if (relu) {
+                const f32x4 ov = reinterpret_cast<const f32x4*>(out)[o];
+#pragma unroll
+                for (int e = 0; e < 4; e++) g[e] = ov[e] > 0.f ? g[e] : 0.f;
+            }
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) r[e] = gi * (g[e] - k0 - (xv[e] - m) * is * k1);
+            if ((k & 3) == 3) r[3] = 0.f, g[3] = 0.f;
+            reinterpret_cast<f32x4*>(dx)[o] = r;
+            if (dres) reinterpret_cast<f32x4*>(dres)[o] = g;
+            ds += (double)((r[0] + r[1]) + (r[2] + r[3]));
         }
+    if (dxsum) {
+        ds = block_sum_256(ds, sh);
+        if (t == 0) dxsum[(size_t)blockIdx.y * dxsum_ld + c] = (float)ds;
+    }
 }
 
 template <int H, int W, bool R16 = false>

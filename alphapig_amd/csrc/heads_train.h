@@ -8,93 +8,103 @@
 #include <hip/hip_runtime.h>
 
 #include "conv3x3_mfma.h"
+#include "conv_train.h"
 #include "sampler.h"
 
 namespace apz {
 
 // ---- 1x1 convolution, C_in -> CO (CO <= 8), over n boards of P = H*W pixels.
 // x / dx: planes with plane stride ps and row stride rs (dense: ps = P, rs = W; padded rows: 240 / 16); y / dy dense
-// [n][CO][P].  One workgroup per board; the weights (CO x C floats) sit in LDS.
+// [n][CO][P].
+// forward: grid (n, ceil(P / 64)); lane = pixel of the workgroup's 64, wave w = the channels w, w + 4, ... (a quarter of
+// the dependent load chain each; round 3 had one workgroup per board and one thread per pixel walking all C channels:
+// 41 us for 128 boards, all of it load latency); the four partial sums meet in LDS in wave order.
 __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int C,
                                                           int CO, int H, int W, int ps, int rs) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CO][C]
-    const int P = H * W, n = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CO][C] weights, [4][8][64] partial sums
+    float* ex = lds + CO * C;
+    const int P = H * W, n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.y * 64 + lane;
     for (int i = threadIdx.x; i < CO * C; i += 256) lds[i] = w[i];
     __syncthreads();
-    const float* xb = x + (size_t)n * C * ps;
-    for (int p = threadIdx.x; p < P; p += 256) {
-        const int off = (p / W) * rs + (p % W);
-        float acc[8];
-#pragma unroll
-        for (int o = 0; o < 8; o++) acc[o] = (o < CO && bias) ? bias[o] : 0.f;
-        for (int c = 0; c < C; c++) {
-            const float v = xb[(size_t)c * ps + off];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p < P) {
+        const float* xb = x + (size_t)n * C * ps + (p / W) * rs + (p % W);
+        for (int c = wave; c < C; c += 4) {
+            const float v = xb[(size_t)c * ps];
 #pragma unroll
             for (int o = 0; o < 8; o++)
                 if (o < CO) acc[o] = __builtin_fmaf(lds[o * C + c], v, acc[o]);
         }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o++) ex[(wave * 8 + o) * 64 + lane] = acc[o];
+    __syncthreads();
+    if (wave == 0 && p < P)
 #pragma unroll
         for (int o = 0; o < 8; o++)
-            if (o < CO) y[((size_t)n * CO + o) * P + p] = acc[o];
-    }
+            if (o < CO)
+                y[((size_t)n * CO + o) * P + p] =
+                    (((ex[o * 64 + lane] + ex[(8 + o) * 64 + lane]) + ex[(16 + o) * 64 + lane]) + ex[(24 + o) * 64 + lane]) +
+                    (bias ? bias[o] : 0.f);
 }
 
 // backward: dx[n][c][p] = sum_o w[o][c] dy[n][o][p]  (written in x's layout, pad cells zero; `accumulate`: added to
 //           what dx holds -- the two heads share one input gradient),
 //           part[n][o][c] = sum_p dy[n][o][p] x[n][c][p]  (per-board partial of dw; summed over n in a fixed order by
 //           colsum_kernel below: no float atomics, results do not depend on arrival order).
+// grid (n, ceil(C / 32)): a workgroup owns 32 channels of a board (one workgroup per board took 92 us for 128 boards:
+// 128 workgroups of dependent loads on 256 CUs).  dw partials: wave w owns the channels 8 w .. 8 w + 7 of the group,
+// lanes walk the pixels (coalesced), the 64 lane sums meet by shuffles.
 __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ dy, float* __restrict__ dx,
                                                           float* __restrict__ part, int C, int CO, int H, int W, int ps,
                                                           int rs, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CO][C] weights, [CO][P] dy
-    const int P = H * W, n = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CO][32] weights of the group, [CO][P] dy
+    const int P = H * W, n = blockIdx.x, c0 = blockIdx.y * 32, nc = min(32, C - c0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* wl = lds;
-    float* dl = lds + CO * C;
-    for (int i = threadIdx.x; i < CO * C; i += 256) wl[i] = w[i];
+    float* dl = lds + CO * 32;
+    for (int i = threadIdx.x; i < CO * 32; i += 256) wl[i] = (i & 31) < nc ? w[(i >> 5) * C + c0 + (i & 31)] : 0.f;
     for (int i = threadIdx.x; i < CO * P; i += 256) dl[i] = dy[(size_t)n * CO * P + i];
     __syncthreads();
-    const float* xb = x + (size_t)n * C * ps;
+    const float* xb = x + ((size_t)n * C + c0) * ps;
     if (dx) {
-        float* dxb = dx + (size_t)n * C * ps;
+        float* dxb = dx + ((size_t)n * C + c0) * ps;
         const int cells = H * rs;                 // cells of a plane, pad cells included (cells <= ps)
-        for (int i = threadIdx.x; i < C * cells; i += 256) {
+        for (int i = threadIdx.x; i < nc * cells; i += 256) {
             const int c = i / cells, q = i - c * cells, row = q / rs, col = q - row * rs;
             float s = 0.f;
             if (col < W) {
                 const int p = row * W + col;
 #pragma unroll
                 for (int o = 0; o < 8; o++)
-                    if (o < CO) s = __builtin_fmaf(wl[o * C + c], dl[o * P + p], s);
+                    if (o < CO) s = __builtin_fmaf(wl[o * 32 + c], dl[o * P + p], s);
                 if (accumulate) s += dxb[(size_t)c * ps + q];
             }
             dxb[(size_t)c * ps + q] = s;
         }
     }
-    // dw partials: thread (c, half) sums over its half of the pixels; the two halves meet through LDS
-    const int c = threadIdx.x % 128, half = threadIdx.x / 128;
-    for (int c0 = 0; c0 < C; c0 += 128) {
+    for (int k = 0; k < 8; k++) {
+        const int c = wave * 8 + k;
+        if (c >= nc) break;                       // wave-uniform
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (c0 + c < C) {
-            const float* xc = xb + (size_t)(c0 + c) * ps;
-            for (int p = half; p < P; p += 2) {
-                const float v = xc[(p / W) * rs + (p % W)];
-#pragma unroll
-                for (int o = 0; o < 8; o++)
-                    if (o < CO) acc[o] = __builtin_fmaf(dl[o * P + p], v, acc[o]);
-            }
-        }
-        __syncthreads();
-        float* ex = lds + CO * C + CO * P;        // [8][128] exchange
-        if (half == 1)
-#pragma unroll
-            for (int o = 0; o < 8; o++) ex[o * 128 + c] = acc[o];
-        __syncthreads();
-        if (half == 0 && c0 + c < C)
+        const float* xc = xb + (size_t)c * ps;
+        for (int p = lane; p < P; p += 64) {
+            const float v = xc[(p / W) * rs + (p % W)];
 #pragma unroll
             for (int o = 0; o < 8; o++)
-                if (o < CO) part[((size_t)n * CO + o) * C + c0 + c] = acc[o] + ex[o * 128 + c];
+                if (o < CO) acc[o] = __builtin_fmaf(dl[o * P + p], v, acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            if (o < CO) {
+                float a = acc[o];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+                if (lane == 0) part[((size_t)n * CO + o) * C + c0 + c] = a;
+            }
     }
 }
 
@@ -102,11 +112,10 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const float* __restric
 // 64 columns, wave w the rows w, w + 4, ...; eight loads are in flight per lane and the four partial sums meet in
 // LDS in wave order.  (One thread per column walking the rows one dependent load at a time took 20 us for a few KB.)
 // Used for dw of the 1x1 convolutions (rows = boards), bias gradients (rows = batch or batch slices) and the loss terms.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
-                                                     float scale) {
+__device__ __forceinline__ void colsum_block(const float* in, float* out, int rows, int cols, float scale, int g) {
     __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
+    const int j = g * 64 + lane;
     double s = 0.0;
     if (j < cols) {
         int i = wave;
@@ -123,11 +132,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     __syncthreads();
     if (wave == 0 && j < cols) out[j] = (float)((((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) * (double)scale);
 }
-
-// part[s][c] = sum over the boards of slice s and the cells of plane c of dy[n][c][.] (planes of `ps` floats: dense, or
-// padded rows whose pad cells are zero); grid (C, slices); colsum_kernel then adds the slices in index order.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ part, int n, int C,
-                                                        int ps) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
+                                                     float scale) {
+    colsum_block(in, out, rows, cols, scale, blockIdx.x);
+}
+// part[c][s] = sum over the boards of slice s and the cells of plane c of dy[n][c][.] (planes of `ps` floats: dense, or
+// padded rows whose pad cells are zero); grid (C, slices); the channel's last workgroup (grid_tail, conv_train.h) adds
+// the slices in a fixed order: db[c].
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* part, float* db,
+                                                        unsigned* __restrict__ counter, int n, int C, int ps) {
     __shared__ double sh[4];
     const int c = blockIdx.x, slices = gridDim.y, sl = blockIdx.y;
     const int b0 = (int)((long)n * sl / slices), b1 = (int)((long)n * (sl + 1) / slices);
@@ -138,11 +151,13 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
         for (int i = threadIdx.x; i < ps; i += 256) t += pl[i];
         s += (double)t;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[(size_t)sl * C + c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) tail_store(part + (size_t)c * slices + sl, (float)s);
+    if (!grid_tail(counter + c, slices)) return;
+    s = 0.0;
+    for (int k = threadIdx.x; k < slices; k += 256) s += (double)tail_load(part + (size_t)c * slices + k);
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) db[c] = (float)s;
 }
 
 // y += x

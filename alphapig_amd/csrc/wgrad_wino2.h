@@ -6,7 +6,7 @@
 //   dg[co][ci]      = G^T dU G                                                             (3x3 from 6x6)
 // i.e. 36 independent [128 x K] x [K x 128] products with K = 16 tiles per board: 9 216 fp32 MFMAs per board instead of the
 // 32 832 of the direct form (conv3x3_wgrad_kernel).  Partial dU of the batch slices go to a scratch tensor;
-// wgrad_wino_sum_kernel / wgrad_wino_reduce_kernel (below) add them and apply G^T . G.
+// wgrad_wino_finish_kernel (below) adds them and applies G^T . G.
 //
 // Round 2's first version (by position groups, in the git history) gave a workgroup three of the 36 positions and all 128 x 128 channel pairs: every board's 256
 // planes are read by twelve workgroups (2.9 MB of L2 -> CU traffic per board, 1.5 GB per 512-board launch), and each of
@@ -328,25 +328,40 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
                         b * 16 + j] = acc[p][a][b][r];
 }
 
-// stage 1: dU[pos][co][ci] = sum over slices (in place into slice 0); one thread per element, 16-byte accesses
-__global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(float* __restrict__ scratch, int slices) {
-    const long i = blockIdx.x * 256L + threadIdx.x;          // float4 index into [36][128][128]
-    if (i >= 36L * 128 * 128 / 4) return;
-    f32x4 a = reinterpret_cast<const f32x4*>(scratch)[i];
-    for (int s = 1; s < slices; s++) a += reinterpret_cast<const f32x4*>(scratch + (size_t)s * 36 * 128 * 128)[i];
-    reinterpret_cast<f32x4*>(scratch)[i] = a;
-}
-
-// stage 2: dw[co][ci][a][b] = sum_{i,k} G[i][a] G[k][b] dU[6i+k][co][ci]   (one thread per (co, ci))
-__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ du, float* __restrict__ dw) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // co * 128 + ci
-    if (idx >= 128 * 128) return;
+// dw[co][ci][a][b] = sum_{i,k} G[i][a] G[k][b] dU[6i+k][co][ci],  dU[pos][co][ci] = sum over the slices' partials in slice
+// order -- one launch (round 3 had a sum launch and a transform launch; the bits are the same: the same order of
+// additions and the same transform expressions).  A workgroup owns 64 consecutive (co, ci) pairs: thread (slot, col) adds
+// the slices of positions slot, slot + 16, slot + 32 for the 16-byte column col (16 lanes = 256 contiguous bytes per slice
+// and position); then 64 threads transform 6x6 -> 3x3 out of LDS.  The launch is bound by reading the partials
+// (slices x 2.36 MB).
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ scratch, int slices,
+                                                                float* __restrict__ dw) {
+    __shared__ f32x4 u4[36][16];
+    const int t = threadIdx.x, col = t & 15, slot = t >> 4;
+    const size_t c4 = (size_t)blockIdx.x * 16 + col;                       // float4 column of [128 co][128 ci]
+    constexpr size_t POS4 = 128 * 128 / 4, SLICE4 = 36 * POS4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(scratch);
+    for (int p = slot; p < 36; p += 16) {
+        f32x4 a = src[(size_t)p * POS4 + c4];
+        int sl = 1;
+        for (; sl + 7 < slices; sl += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = src[(size_t)(sl + k) * SLICE4 + (size_t)p * POS4 + c4];
+#pragma unroll
+            for (int k = 0; k < 8; k++) a += v[k];
+        }
+        for (; sl < slices; sl++) a += src[(size_t)sl * SLICE4 + (size_t)p * POS4 + c4];
+        u4[p][col] = a;
+    }
+    __syncthreads();
+    if (t >= 64) return;
     const float G[6][3] = {{0.25f, 0.f, 0.f},           {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                            {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
     float u[36];
 #pragma unroll
-    for (int p = 0; p < 36; p++) u[p] = du[(size_t)p * (128 * 128) + idx];
-    float t[3][6];                                   // t[a][k] = sum_i G[i][a] dU[i][k]
+    for (int p = 0; p < 36; p++) u[p] = reinterpret_cast<const float*>(&u4[p][0])[t];
+    float tt[3][6];                                  // tt[a][k] = sum_i G[i][a] dU[i][k]
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -354,16 +369,17 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __r
             float v = 0.f;
 #pragma unroll
             for (int i = 0; i < 6; i++) v += G[i][a] * u[i * 6 + k];
-            t[a][k] = v;
+            tt[a][k] = v;
         }
+    const size_t idx = (size_t)blockIdx.x * 64 + t;          // co * 128 + ci
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
         for (int b2 = 0; b2 < 3; b2++) {
             float v = 0.f;
 #pragma unroll
-            for (int k = 0; k < 6; k++) v += t[a][k] * G[k][b2];
-            dw[(size_t)idx * 9 + a * 3 + b2] = v;
+            for (int k = 0; k < 6; k++) v += tt[a][k] * G[k][b2];
+            dw[idx * 9 + a * 3 + b2] = v;
         }
 }
 

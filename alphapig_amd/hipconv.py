@@ -69,8 +69,26 @@ def is_trunk_shape(weight, x, layout):
 
 
 # ---- 3x3 convolution ------------------------------------------------------------------------------------------------
-def _conv3x3_run(x, weight, bias, layout, flip, resid, relu):
-    """conv(x, W) (flip: the data-gradient convolution with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]) + bias + resid."""
+def wino_pack_many(weights, out=None):
+    """weights [count][128][128][3][3] (one contiguous tensor) -> [count][2][apz_wino_packed_size()]: every layer's
+    transformed weights for the forward convolution ([:, 0]) and the data-gradient convolution ([:, 1]), one launch."""
+    torch = _torch()
+    if not (weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous() and
+            tuple(weights.shape[1:]) == (128, 128, 3, 3)):
+        raise ValueError("wino_pack_many takes a contiguous float32 device tensor [count][128][128][3][3]")
+    L = _native.hip()
+    hnd = _engine(15, 15, weights.device.index or 0)
+    count = int(weights.shape[0])
+    if out is None:
+        out = _empty((count, 2, L.apz_wino_packed_size()), weights)
+    stream = C.c_void_p(torch.cuda.current_stream(weights.device).cuda_stream)
+    _ck(L, L.apz_wino_pack_many(hnd, weights.data_ptr(), count, out.data_ptr(), stream))
+    return out
+
+
+def _conv3x3_run(x, weight, bias, layout, flip, resid, relu, upk=None):
+    """conv(x, W) (flip: the data-gradient convolution with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]) + bias + resid.
+    upk: the layer's transformed weights in that orientation when the caller packed them already (wino_pack_many)."""
     L, hnd, stream = _ctx(x, layout)
     co, ci = int(weight.shape[0]), int(weight.shape[1])
     cin_p, cout_p = (co, ci) if flip else (ci, co)
@@ -82,8 +100,9 @@ def _conv3x3_run(x, weight, bias, layout, flip, resid, relu):
     # direct kernel (measured round 1: 24.2 vs 31.0 ms per training step at batch 512, 12.3 vs 11.8 ms at 128);
     # padded-row tensors are its native layout and always take it
     if is_trunk_shape(weight, x, layout) and (layout == ROWS16 or n >= 192):
-        upk = _empty((L.apz_wino_packed_size(),), x)
-        _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), int(flip), upk.data_ptr(), stream))
+        if upk is None:
+            upk = _empty((L.apz_wino_packed_size(),), x)
+            _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), int(flip), upk.data_ptr(), stream))
         if resid is not None and layout != ROWS16:
             _ck(L, L.apz_wino_conv_add(hnd, x.data_ptr(), upk.data_ptr(), _ptr(bias), None, y.data_ptr(), n, 0, layout, stream))
             add_(y, resid)
@@ -106,15 +125,15 @@ def _conv3x3_run(x, weight, bias, layout, flip, resid, relu):
     return y
 
 
-def conv3x3_fwd(x, weight, bias=None, layout=DENSE, relu=False):
+def conv3x3_fwd(x, weight, bias=None, layout=DENSE, relu=False, upk=None):
     """y = conv2d(x, weight, bias, padding=1).  Dense: boards 15x15 or 8x8, C_out in {64, 128, 256}."""
-    return _conv3x3_run(x, weight, bias, layout, False, None, relu)
+    return _conv3x3_run(x, weight, bias, layout, False, None, relu, upk)
 
 
-def conv3x3_dgrad(dy, weight, layout=DENSE, add=None):
+def conv3x3_dgrad(dy, weight, layout=DENSE, add=None, upk=None):
     """dx = conv2d_input(dy, weight) (+ add: another gradient of the same tensor, e.g. the skip connection's).
     Needs C_in in {64, 128, 256} (the first layer's input gradient is never wanted)."""
-    return _conv3x3_run(dy, weight, None, layout, True, add, False)
+    return _conv3x3_run(dy, weight, None, layout, True, add, False, upk)
 
 
 def conv3x3_wgrad(x, dy, layout=DENSE):
@@ -160,16 +179,45 @@ def bn_fwd(x, gamma, beta, run_mean, run_var, resid=None, relu=True, layout=DENS
     return y, mean, invstd
 
 
-def bn_bwd(dy, x, y, gamma, mean, invstd, relu=True, want_dres=False, layout=DENSE):
-    """-> (dx, dres or None, dgamma, dbeta); y is the forward output (the ReLU mask)."""
+def bn_bwd(dy, x, y, gamma, mean, invstd, relu=True, want_dres=False, layout=DENSE, dxsum=None):
+    """-> (dx, dres or None, dgamma, dbeta); y is the forward output (the ReLU mask).
+    dxsum: a [bn_bwd_splits(x, layout)][C] view (row stride >= C) of a float32 matrix that receives the per-split column
+    sums of dx -- colsum() of it is the bias gradient of the convolution in front (bias_parts() hands such views out)."""
     L, hnd, stream = _ctx(x, layout)
     n, c = int(x.shape[0]), int(x.shape[1])
     dx = _empty(tuple(x.shape), x)
     dres = _empty(tuple(x.shape), x) if want_dres else None
     dgamma, dbeta = _empty((c,), x), _empty((c,), x)
+    ld = 0
+    if dxsum is not None:
+        if tuple(dxsum.shape) != (bn_bwd_splits(x, layout), c) or dxsum.stride(1) != 1:
+            raise ValueError("dxsum: a [splits][C] view with unit column stride")
+        ld = int(dxsum.stride(0))
     _ck(L, L.apz_bn_bwd(hnd, dy.data_ptr(), x.data_ptr(), y.data_ptr(), _ptr(gamma), mean.data_ptr(), invstd.data_ptr(),
-                        dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n, c, layout, int(relu), stream))
+                        dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dxsum), ld, n, c, layout, int(relu),
+                        stream))
     return dx, dres, dgamma, dbeta
+
+
+def bn_bwd_splits(x, layout=DENSE):
+    """rows of bn_bwd's dxsum matrix for tensors of x's shape"""
+    L, hnd, _ = _ctx(x, layout)
+    s = L.apz_bn_bwd_splits(hnd, int(x.shape[0]), int(x.shape[1]), layout)
+    _ck(L, s)
+    return int(s)
+
+
+def colsum(m, scale=1.0):
+    """out[j] = scale * sum_i m[i][j] (fixed order, double accumulation); m: contiguous [rows][cols] float32"""
+    torch = _torch()
+    if not (m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() and m.dim() == 2):
+        raise ValueError("colsum takes a contiguous float32 device matrix")
+    L = _native.hip()
+    hnd = _any_engine(m.device.index or 0)
+    out = _empty((int(m.shape[1]),), m)
+    stream = C.c_void_p(torch.cuda.current_stream(m.device).cuda_stream)
+    _ck(L, L.apz_colsum(hnd, m.data_ptr(), out.data_ptr(), int(m.shape[0]), int(m.shape[1]), scale, stream))
+    return out
 
 
 # ---- heads ----------------------------------------------------------------------------------------------------------

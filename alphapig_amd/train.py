@@ -81,6 +81,16 @@ class HipTrainer(object):
         # the self-play kernels' padded-row layout for the trunk when the net has their shape
         self.rows16 = (net_kind == "resnet" and n_blocks > 0 and self.side == 15 and
                        tuple(self.p["convA1_weight"].shape) == (128, 128, 3, 3))
+        # ... whose 2 n_blocks weight tensors then live back to back in one buffer (self.p holds views): one launch packs
+        # all of them for the Winograd kernel in both orientations at the start of a step (hipconv.wino_pack_many)
+        self._trunk_names = []
+        self._trunk_w = self._upk = None
+        if self.rows16:
+            self._trunk_names = ["conv%s%d_weight" % (ab, i) for i in range(1, n_blocks + 1) for ab in "AB"]
+            self._trunk_w = torch.empty((len(self._trunk_names), 128, 128, 3, 3), dtype=torch.float32, device=self.device)
+            for j, k in enumerate(self._trunk_names):
+                self._trunk_w[j].copy_(self.p[k])
+                self.p[k] = self._trunk_w[j]
         self._eval = None
         self._eval_t = -1
         self.tape = None
@@ -120,14 +130,18 @@ class HipTrainer(object):
             x, rec = self._conv_act_fwd(states, "res_conv1", o.DENSE)
             tape["stem"] = rec
             lay = o.ROWS16 if self.rows16 else o.DENSE
+            upk = None
             if self.rows16:
                 x = o.to_rows16(x)
+                self._upk = upk = o.wino_pack_many(self._trunk_w, self._upk)
+            tape["upk"] = upk
             for i in range(1, self.n_blocks + 1):
                 A, B = "A%d" % i, "B%d" % i
-                ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay)
+                ua, ub = (upk[2 * i - 2, 0], upk[2 * i - 1, 0]) if upk is not None else (None, None)
+                ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay, upk=ua)
                 ha, ma, ia = o.bn_fwd(ya, p["bn" + A + "_gamma"], p["bn" + A + "_beta"], p["bn" + A + "_moving_mean"],
                                       p["bn" + A + "_moving_var"], None, True, lay, 1.0 - BN_MOMENTUM, BN_EPS)
-                yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay)
+                yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay, upk=ub)
                 out, mb, ib = o.bn_fwd(yb, p["bn" + B + "_gamma"], p["bn" + B + "_beta"], p["bn" + B + "_moving_mean"],
                                        p["bn" + B + "_moving_var"], x, True, lay, 1.0 - BN_MOMENTUM, BN_EPS)
                 tape["blocks"].append((x, ya, ha, ma, ia, yb, out, mb, ib))
@@ -166,19 +180,28 @@ class HipTrainer(object):
         dx = self._conv_act_bwd(dpol.view(n, 4, self.side, self.side), tape["pol"], True)
         dx = self._conv_act_bwd(dval.view(n, 2, self.side, self.side), tape["val"], True, dx_acc=dx)
         if self.kind == "resnet":
-            for i in range(self.n_blocks, 0, -1):
+            upk = tape.get("upk")
+            # the trunk convolutions' bias gradients = column sums of the dx their BatchNorms hand back: every bn_bwd
+            # leaves its per-split sums in its own columns of ONE matrix, added after the loop in one launch
+            nb, nf = self.n_blocks, int(tape["blocks"][0][1].shape[1])
+            parts = o._empty((o.bn_bwd_splits(tape["blocks"][0][1], lay), 2 * nb * nf), dx)
+            for i in range(nb, 0, -1):
                 A, B = "A%d" % i, "B%d" % i
                 x, ya, ha, ma, ia, yb, out, mb, ib = tape["blocks"][i - 1]
+                ua, ub = (upk[2 * i - 2, 1], upk[2 * i - 1, 1]) if upk is not None else (None, None)
+                ca, cb = (2 * i - 2) * nf, (2 * i - 1) * nf
                 dyb, dskip, g["bn" + B + "_gamma"], g["bn" + B + "_beta"] = o.bn_bwd(dx, yb, out, p["bn" + B + "_gamma"], mb, ib,
-                                                                                    True, True, lay)
+                                                                                    True, True, lay, dxsum=parts[:, cb:cb + nf])
                 g["conv" + B + "_weight"] = o.conv3x3_wgrad(ha, dyb, lay)
-                g["conv" + B + "_bias"] = o.bias_grad(dyb, lay)
-                dha = o.conv3x3_dgrad(dyb, p["conv" + B + "_weight"], lay)
+                dha = o.conv3x3_dgrad(dyb, p["conv" + B + "_weight"], lay, upk=ub)
                 dya, _, g["bn" + A + "_gamma"], g["bn" + A + "_beta"] = o.bn_bwd(dha, ya, ha, p["bn" + A + "_gamma"], ma, ia,
-                                                                                True, False, lay)
+                                                                                True, False, lay, dxsum=parts[:, ca:ca + nf])
                 g["conv" + A + "_weight"] = o.conv3x3_wgrad(x, dya, lay)
-                g["conv" + A + "_bias"] = o.bias_grad(dya, lay)
-                dx = o.conv3x3_dgrad(dya, p["conv" + A + "_weight"], lay, add=dskip)   # trunk + skip gradients meet
+                dx = o.conv3x3_dgrad(dya, p["conv" + A + "_weight"], lay, add=dskip, upk=ua)   # trunk + skip gradients meet
+            db = o.colsum(parts)
+            for i in range(1, nb + 1):
+                g["convA%d_bias" % i] = db[(2 * i - 2) * nf:(2 * i - 1) * nf]
+                g["convB%d_bias" % i] = db[(2 * i - 1) * nf:2 * i * nf]
             if self.rows16:
                 dx = o.from_rows16(dx)
             self._conv_act_bwd(dx, tape["stem"], False)

@@ -157,6 +157,10 @@ int apz_conv3x3_wgrad(apz_engine *e, const void *x_dev, const void *dy_dev, void
  *                   (copied to / from the kernel's padded-row layout in engine-owned scratch) */
 int64_t apz_wino_packed_size(void);
 int apz_wino_pack(apz_engine *e, const void *w_dev, int transpose_flip, void *upk_dev, void *stream);
+/* ... of `count` layers whose weights lie back to back (w_dev [count][128][128][3][3]) in both orientations, one launch:
+ * upk_dev [count][2][apz_wino_packed_size()] (forward, data gradient).  A training step packs every trunk layer twice
+ * (policy_value_net_mxnet.py:282-299: the weights change with every optimiser step). */
+int apz_wino_pack_many(apz_engine *e, const void *w_dev, int count, void *upk_dev, void *stream);
 int apz_wino_conv(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev,
                   void *y_dev, int n, int relu, int layout, void *stream);
 /* ... + resid_dev (padded-row layout only; NULL: none) before the ReLU: the data gradient of a residual block's first
@@ -170,7 +174,15 @@ int apz_wino_conv_add(apz_engine *e, const void *x_dev, const void *upk_dev, con
  *               (may be NULL) updated as run = (1 - momentum) * run + momentum * batch (unbiased variance);
  *               gamma_dev NULL = 1 (the reference's fix_gamma layers)
  *   apz_bn_bwd  dz = dy (* [out > 0] with relu); dbeta = sum dz; dgamma = sum dz * xhat;
- *               dx = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M); dres = dz (NULL: not wanted) */
+ *               dx = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M); dres = dz (NULL: not wanted);
+ *               dxsum_dev (NULL: not wanted): [apz_bn_bwd_splits(n, C, layout)][dxsum_ld] floats, dxsum_ld >= C;
+ *               row s, column c gets the sum of channel c's dx over the boards of batch split s.  The column
+ *               sums (apz_colsum) are the bias gradient of the convolution that produced x; a caller with
+ *               several layers gives each its own C columns of one matrix and adds them all in one launch.
+ * Channel sums: double precision, per (channel, batch split) partials (no atomics) that every consumer workgroup
+ * adds in a fixed order (csrc/conv_train.h) -- two launches per call, the same bits on every run.  The training
+ * entry points share per-engine scratch: calls on one engine must be ordered by ONE stream at a time.
+ *   apz_colsum  out[j] = scale * sum_i in[i][j] over rows x cols floats, fixed order (double accumulation) */
 int apz_bn_fwd(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
                const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
                void *invstd_dev, int n, int C, int layout, int relu, float momentum, float eps, void *stream);
@@ -187,8 +199,10 @@ int apz_adam_step(apz_engine *e, const void *table_host, int ntensors, float lr_
                   float eps, float rescale, void *stream);
 int apz_bn_bwd(apz_engine *e, const void *dy_dev, const void *x_dev, const void *out_dev,
                const void *gamma_dev, const void *mean_dev, const void *invstd_dev, void *dx_dev,
-               void *dres_dev, void *dgamma_dev, void *dbeta_dev, int n, int C, int layout, int relu,
-               void *stream);
+               void *dres_dev, void *dgamma_dev, void *dbeta_dev, void *dxsum_dev, int dxsum_ld, int n, int C,
+               int layout, int relu, void *stream);
+int apz_bn_bwd_splits(apz_engine *e, int n, int C, int layout);
+int apz_colsum(apz_engine *e, const void *in_dev, void *out_dev, int rows, int cols, float scale, void *stream);
 
 /* ---- heads and loss of the training graph (policy_value_net_mxnet.py:85-102, :173-193), csrc/heads_train.h.
  * All tensors float32 on the device; `layout` as above for the trunk-side tensors (x, dx); y / dy dense.

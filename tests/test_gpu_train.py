@@ -136,8 +136,21 @@ def test_bn_forward_backward(layout, relu, resid, gamma, c):
     gc, bc = ga.cuda(), be.cuda()
     rmc, rvc = rm.cuda(), rv.cuda()
     y, mean, invstd = hipconv.bn_fwd(xc, gc if gamma else None, bc, rmc, rvc, rc if resid else None, relu, layout, 0.1, 1e-3)
-    dx, dres, dgamma, dbeta = hipconv.bn_bwd(pad(dy).cuda(), xc, y, gc if gamma else None, mean, invstd, relu, resid, layout)
+    # dxsum: this layer's columns of a wider matrix (the trainer gives every trunk layer its own columns)
+    parts = torch.full((hipconv.bn_bwd_splits(xc, layout), c + 40), 7.0, device="cuda")
+    dx, dres, dgamma, dbeta = hipconv.bn_bwd(pad(dy).cuda(), xc, y, gc if gamma else None, mean, invstd, relu, resid, layout,
+                                             dxsum=parts[:, 8:8 + c])
+    db = hipconv.colsum(parts)
+    dx_b, _, dgamma_b, dbeta_b = hipconv.bn_bwd(pad(dy).cuda(), xc, y, gc if gamma else None, mean, invstd, relu, resid, layout)
     torch.cuda.synchronize()
+    # the column sums of dx = what apz_bias_grad makes of the same tensor (rounding noise around zero: dx sums to 0 per
+    # channel analytically); columns outside the layer's are untouched; no atomics anywhere: a second call, the same bits
+    ref_db = dx.double().sum(dim=(0, 2, 3)).cpu()
+    scale = float(dx.abs().sum(dim=(0, 2, 3)).max())
+    assert float((db[8:8 + c].cpu().double() - ref_db).abs().max()) < 1e-6 * scale
+    assert float((hipconv.bias_grad(dx, layout).cpu().double() - ref_db).abs().max()) < 1e-6 * scale
+    assert float((db[:8] - 7.0 * parts.shape[0]).abs().max()) == 0.0 and float((db[8 + c:] - 7.0 * parts.shape[0]).abs().max()) == 0.0
+    assert torch.equal(dx, dx_b) and torch.equal(dbeta, dbeta_b) and torch.equal(dgamma, dgamma_b)
     cut = (lambda t: t[..., :15]) if layout == 1 else (lambda t: t)
     if layout == 1:
         assert float(y[..., 15].abs().max()) == 0.0
@@ -153,6 +166,36 @@ def test_bn_forward_backward(layout, relu, resid, gamma, c):
     else:
         assert dres is None
     assert close(rmc, rm64, 1e-5) and close(rvc, rv64, 1e-5)
+
+
+@pytest.mark.parametrize("n,layout,c", [(130, 1, 128), (515, 1, 128), (300, 0, 4), (300, 0, 128)])
+def test_bn_batch_splits(n, layout, c):
+    """... at batch sizes that give every channel several batch splits (padded rows: four boards per trip and split): the
+    consumers' sum of the per-split partials against float64, and the same bits on a second run."""
+    from alphapig_amd import hipconv
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, 15, 15, generator=g) * 0.8 - 0.2
+    dy = torch.randn(n, c, 15, 15, generator=g)
+    be = torch.randn(c, generator=g) * 0.2
+    x64, be64 = x.double().requires_grad_(True), be.double().requires_grad_(True)
+    y64 = torch.relu(F.batch_norm(x64, None, None, torch.ones(c, dtype=torch.float64), be64, training=True, eps=1e-3))
+    y64.backward(dy.double())
+    pad = pad16 if layout == 1 else (lambda t: t)
+    cut = (lambda t: t[..., :15]) if layout == 1 else (lambda t: t)
+    xc, dyc, bc = pad(x).cuda(), pad(dy).cuda(), be.cuda()
+    assert hipconv.bn_bwd_splits(xc, layout) > 1
+    outs = []
+    for _ in range(2):
+        y, mean, invstd = hipconv.bn_fwd(xc, None, bc, None, None, None, True, layout, 0.1, 1e-3)
+        dx, _, _, dbeta = hipconv.bn_bwd(dyc, xc, y, None, mean, invstd, True, False, layout)
+        outs.append((y, mean, invstd, dx, dbeta))
+    torch.cuda.synchronize()
+    close = lambda a, b, t: float((a.cpu().double() - b).abs().max()) < t * (float(b.abs().max()) + 1e-3)
+    y, mean, invstd, dx, dbeta = outs[0]
+    assert close(cut(y), y64.detach(), 1e-5) and close(cut(dx), x64.grad, 1e-4) and close(dbeta, be64.grad, 1e-5)
+    assert close(mean, x.double().mean(dim=(0, 2, 3)), 1e-6)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("n,c,co,hw,layout", [(9, 128, 4, 15, 1), (9, 128, 2, 15, 1), (5, 128, 4, 15, 0), (6, 256, 4, 8, 0),
