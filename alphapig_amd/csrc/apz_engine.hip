@@ -1604,7 +1604,7 @@ int apz_adam_step(apz_engine* e, const void* table_host, int ntensors, float lr_
 
 // ---- heads and loss of the training graph (csrc/heads_train.h)
 namespace {
-// C[M][N] = A B (+ bias): 64 x 64 tiles per workgroup when those fill the chip, else 64 x 16
+// C[M][N] = A B (+ bias): 64 x 64 tiles per workgroup when those fill the chip, else 16 x 16 tiles with the k-steps split over the waves
 void launch_sgemm(apz_engine* e, const float* a, const float* b, const float* bias, float* c, int M, int N, int K, long a_rs,
                   long a_cs, long b_rs, long b_cs, int ldc) {
     const int my = (M + 63) / 64;
@@ -1612,8 +1612,8 @@ void launch_sgemm(apz_engine* e, const float* a, const float* b, const float* bi
         hipLaunchKernelGGL(apz::sgemm_mfma_kernel<4>, dim3((N + 63) / 64, my), dim3(256), 0, e->stream, a, b, bias, c, M, N, K, a_rs,
                            a_cs, b_rs, b_cs, ldc);
     else
-        hipLaunchKernelGGL(apz::sgemm_mfma_kernel<1>, dim3((N + 15) / 16, my), dim3(256), 0, e->stream, a, b, bias, c, M, N, K, a_rs,
-                           a_cs, b_rs, b_cs, ldc);
+        hipLaunchKernelGGL(apz::sgemm_ksplit_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, e->stream, a, b, bias, c, M,
+                           N, K, a_rs, a_cs, b_rs, b_cs, ldc);
 }
 
 int head_scratch(apz_engine* e, size_t floats) {

@@ -86,25 +86,43 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const float* __restric
             dxb[(size_t)c * ps + q] = s;
         }
     }
-    for (int k = 0; k < 8; k++) {
-        const int c = wave * 8 + k;
-        if (c >= nc) break;                       // wave-uniform
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* xc = xb + (size_t)c * ps;
-        for (int p = lane; p < P; p += 64) {
-            const float v = xc[(p / W) * rs + (p % W)];
+    // all of the wave's loads first (8 channels x up to 4 pixels per lane in flight: one channel after the other, each
+    // behind its own shuffle tree, was 8 dependent memory round trips), then the products and the lane sums
+    const int ppl = (P + 63) / 64;                // pixels per lane (15x15: 4; 8x8: 1)
+    for (int p0 = 0; p0 < ppl; p0 += 4) {         // (boards up to 16x16 in one pass)
+        float v[8][4];
+        int off[4];
+        bool ok[4];
 #pragma unroll
-            for (int o = 0; o < 8; o++)
-                if (o < CO) acc[o] = __builtin_fmaf(dl[o * P + p], v, acc[o]);
+        for (int j = 0; j < 4; j++) {
+            const int p = (p0 + j) * 64 + lane;
+            ok[j] = p0 + j < ppl && p < P;
+            off[j] = ok[j] ? (p / W) * rs + (p % W) : 0;
         }
 #pragma unroll
-        for (int o = 0; o < 8; o++)
-            if (o < CO) {
-                float a = acc[o];
+        for (int k = 0; k < 8; k++) {
+            const int c = min(wave * 8 + k, nc - 1);
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-                if (lane == 0) part[((size_t)n * CO + o) * C + c0 + c] = a;
-            }
+            for (int j = 0; j < 4; j++) v[k][j] = xb[(size_t)c * ps + off[j]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = wave * 8 + k;
+#pragma unroll
+            for (int o = 0; o < 8; o++)
+                if (o < CO) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (ok[j]) a = __builtin_fmaf(dl[o * P + (p0 + j) * 64 + lane], v[k][j], a);
+#pragma unroll
+                    for (int off2 = 32; off2 > 0; off2 >>= 1) a += __shfl_down(a, off2, 64);
+                    if (lane == 0 && c < nc) {
+                        float* dst = part + ((size_t)n * CO + o) * C + c0 + c;
+                        *dst = p0 ? *dst + a : a;
+                    }
+                }
+        }
     }
 }
 
@@ -211,6 +229,50 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
             const int mm = m0 + 4 * kq + g;
             if (mm < M) c[(size_t)mm * ldc + nn] = acc[t][g] + bb;
         }
+    }
+}
+
+// ... for outputs of few tiles (the policy head's y = x W^T is 128 x 225 x 900 at the reference's batch size: 30
+// workgroups of sgemm_mfma_kernel<1>, each wave 225 dependent k-steps of one load pair = 105 us): a workgroup owns ONE
+// 16 x 16 tile of C, its four waves split the k-steps (wave w: steps w, w + 4, ...), eight steps' loads are issued
+// before their MFMAs, and the four partial tiles meet in LDS in wave order.
+__global__ __launch_bounds__(256) void sgemm_ksplit_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ bias, float* __restrict__ c, int M, int N,
+                                                           int K, long a_rs, long a_cs, long b_rs, long b_cs, int ldc) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    const bool mrow = m0 + r < M, ncol = n0 + r < N;
+    const float* ap = a + (long)(mrow ? m0 + r : 0) * a_rs;
+    const float* bp = b + (long)(ncol ? n0 + r : 0) * b_cs;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int k0 = 4 * wave; k0 < K; k0 += 16 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = k0 + 16 * u + kq;
+            const bool in = k < K;
+            av[u] = ap[(long)(in ? k : 0) * a_cs];
+            bv[u] = bp[(long)(in ? k : 0) * b_rs];
+            if (!in || !mrow) av[u] = 0.f;
+            if (!in || !ncol) bv[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave) return;
+    acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
+    // D layout: column = lane & 15, row = 4 * (lane >> 4) + reg
+    if (!ncol) return;
+    const float bb = bias ? bias[n0 + r] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int mm = m0 + 4 * kq + g;
+        if (mm < M) c[(size_t)mm * ldc + n0 + r] = acc[g] + bb;
     }
 }
 
