@@ -1572,7 +1572,7 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     }
     hipLaunchKernelGGL(apz::wgrad_wino2_kernel, dim3(T2::BLOCKS * slices), dim3(T2::THREADS), T2::LDS_BYTES, e->stream,
                        (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
-    hipLaunchKernelGGL(apz::wgrad_wino_finish_kernel, dim3(128 * 128 / 64), dim3(256), 0, e->stream,
+    hipLaunchKernelGGL(apz::wgrad_wino_finish_kernel, dim3(128 * 128 * 9 / 4 / 256), dim3(256), 0, e->stream,
                        (const float*)e->wgw_scratch, slices, (float*)dw_dev);
     HIP_TRY(hipGetLastError());
     return APZ_OK;

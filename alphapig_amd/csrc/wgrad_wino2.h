@@ -5,8 +5,8 @@
 //   dU[pos][co][ci] = sum over boards and tiles of dM[pos][co][tile] * V[pos][ci][tile],  dM = A dY A^T (6x6 from 4x4),
 //   dg[co][ci]      = G^T dU G                                                             (3x3 from 6x6)
 // i.e. 36 independent [128 x K] x [K x 128] products with K = 16 tiles per board: 9 216 fp32 MFMAs per board instead of the
-// 32 832 of the direct form (conv3x3_wgrad_kernel).  Partial dU of the batch slices go to a scratch tensor;
-// wgrad_wino_finish_kernel (below) adds them and applies G^T . G.
+// 32 832 of the direct form (conv3x3_wgrad_kernel).  Every workgroup applies G^T . G to its own partial dU (epilogue) and
+// writes a partial dg of its batch slice to a scratch tensor; wgrad_wino_finish_kernel (below) adds the slices.
 //
 // Round 2's first version (by position groups, in the git history) gave a workgroup three of the 36 positions and all 128 x 128 channel pairs: every board's 256
 // planes are read by twelve workgroups (2.9 MB of L2 -> CU traffic per board, 1.5 GB per 512-board launch), and each of
@@ -57,9 +57,9 @@ struct WgradWino2 {
 };
 static_assert(WgradWino2::LDS_BYTES <= 160 * 1024, "LDS");
 
-// partial dU of one batch slice: [36][128 co][128 ci]
+// partial weight gradient of one batch slice: [128 co][128 ci][3][3]
 struct WgradWino {
-    static constexpr size_t SCRATCH_FLOATS_PER_SLICE = (size_t)36 * 128 * 128;
+    static constexpr size_t SCRATCH_FLOATS_PER_SLICE = (size_t)128 * 128 * 9;
 };
 
 // rows of B^T (6x6) and of A (6x4): the workgroup's position row is a runtime value, so the first transform stage is
@@ -88,7 +88,7 @@ __device__ __forceinline__ float wgw_quad_neighbour(float v, int k) {
 }
 
 
-// x, dy: padded-row layout [n][128][15][16].  scratch: [slices][36][128 co][128 ci] (partial dU per batch slice).
+// x, dy: padded-row layout [n][128][15][16].  scratch: [slices][128 co][128 ci][3][3] (partial dg per batch slice).
 // Grid: 8 * BLOCKS * spx workgroups, slices = 8 * spx.  Workgroup L (dispatched round-robin over the XCDs, L mod 8 = its
 // XCD) takes slice (L mod 8) * spx + (L / 8) / BLOCKS and channel block (L / 8) mod BLOCKS: the eight blocks of a slice
 // read the same boards and sit on one XCD, so all but the first read of a plane is an L2 hit.
@@ -313,74 +313,78 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
             }
         }
     }
-    // ---- partial dU of this slice and channel block: accumulator (p, a, b), lane (q, j), register r ->
-    // pos = 9 pg + p, co = 64 cob + 16 (2 cc + a) + 4 q + r, ci = 32 cib + 16 b + j
-    float* out = scratch + (size_t)slice * WgradWino::SCRATCH_FLOATS_PER_SLICE;
+    // ---- partial dg of this slice and channel block.  accumulator (p, a, b), lane (q, j), register r holds dU at
+    // pos = 9 pg + p, co = 64 cob + 16 (2 cc + a) + 4 q + r, ci = 32 cib + 16 b + j.  The 36 positions of a (co, ci) pair
+    // sit in four waves: they meet in LDS (free now), half of the block's output channels per pass
+    // ([36][32 co][32 ci + 1 pad] = 152 KB), and every thread turns two pairs' 6x6 into the 3x3 weight gradient
+    // G^T dU G -- the slices' partials are 9 instead of 36 floats per pair: 18.9 MB written and read back per launch
+    // instead of 75.5 MB (round 3: 64-byte pieces written at the very end of every workgroup at once, then a 12 us
+    // sum; together the "39 us fixed per launch" of profiles/r03_train_bench.md).
+    constexpr int CS = 33, PST = 32 * CS;
+    static_assert(36 * PST <= T::LDS_FLOATS, "epilogue staging fits the operand memory");
+    float* du = lds;
+    float* outw = scratch + (size_t)slice * WgradWino::SCRATCH_FLOATS_PER_SLICE;
+    const float G[6][3] = {{0.25f, 0.f, 0.f},           {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
 #pragma unroll
-    for (int p = 0; p < 9; p++)
+    for (int a = 0; a < 2; a++) {
+        __syncthreads();                              // the last half's operand reads / the previous pass's readers are done
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int p = 0; p < 9; p++)
 #pragma unroll
             for (int b = 0; b < 2; b++)
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    out[((size_t)(pg * 9 + p) * T::C + cob * T::CO_B + (2 * cc + a) * 16 + 4 * q + r) * T::C + cib * T::CI_B +
-                        b * 16 + j] = acc[p][a][b][r];
+                for (int r = 0; r < 4; r++) du[(pg * 9 + p) * PST + (cc * 16 + 4 * q + r) * CS + b * 16 + j] = acc[p][a][b][r];
+        __syncthreads();
+#pragma unroll
+        for (int e0 = 0; e0 < 1024; e0 += T::THREADS) {
+            const int e = e0 + tid, col = e >> 5, cil = e & 31;
+            float u[36];
+#pragma unroll
+            for (int p = 0; p < 36; p++) u[p] = du[p * PST + col * CS + cil];
+            float tt[3][6];                          // tt[x][k] = sum_i G[i][x] dU[i][k]
+#pragma unroll
+            for (int x3 = 0; x3 < 3; x3++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i6 = 0; i6 < 6; i6++) v += G[i6][x3] * u[i6 * 6 + k];
+                    tt[x3][k] = v;
+                }
+            const int co = cob * T::CO_B + (2 * (col >> 4) + a) * 16 + (col & 15), ci = cib * T::CI_B + cil;
+            float* d = outw + ((size_t)co * T::C + ci) * 9;
+#pragma unroll
+            for (int x3 = 0; x3 < 3; x3++)
+#pragma unroll
+                for (int y3 = 0; y3 < 3; y3++) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v += tt[x3][k] * G[k][y3];
+                    d[x3 * 3 + y3] = v;
+                }
+        }
+    }
 }
 
-// dw[co][ci][a][b] = sum_{i,k} G[i][a] G[k][b] dU[6i+k][co][ci],  dU[pos][co][ci] = sum over the slices' partials in slice
-// order -- one launch (round 3 had a sum launch and a transform launch; the bits are the same: the same order of
-// additions and the same transform expressions).  A workgroup owns 64 consecutive (co, ci) pairs: thread (slot, col) adds
-// the slices of positions slot, slot + 16, slot + 32 for the 16-byte column col (16 lanes = 256 contiguous bytes per slice
-// and position); then 64 threads transform 6x6 -> 3x3 out of LDS.  The launch is bound by reading the partials
-// (slices x 2.36 MB).
+// dw[co][ci][3][3] = sum over the slices' partials, in slice order (16-byte accesses; 0.59 MB per slice)
 __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ scratch, int slices,
                                                                 float* __restrict__ dw) {
-    __shared__ f32x4 u4[36][16];
-    const int t = threadIdx.x, col = t & 15, slot = t >> 4;
-    const size_t c4 = (size_t)blockIdx.x * 16 + col;                       // float4 column of [128 co][128 ci]
-    constexpr size_t POS4 = 128 * 128 / 4, SLICE4 = 36 * POS4;
-    const f32x4* src = reinterpret_cast<const f32x4*>(scratch);
-    for (int p = slot; p < 36; p += 16) {
-        f32x4 a = src[(size_t)p * POS4 + c4];
-        int sl = 1;
-        for (; sl + 7 < slices; sl += 8) {
-            f32x4 v[8];
+    constexpr size_t N4 = WgradWino::SCRATCH_FLOATS_PER_SLICE / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N4) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(scratch) + i;
+    f32x4 a = src[0];
+    int sl = 1;
+    for (; sl + 7 < slices; sl += 8) {
+        f32x4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = src[(size_t)(sl + k) * SLICE4 + (size_t)p * POS4 + c4];
+        for (int k = 0; k < 8; k++) v[k] = src[(size_t)(sl + k) * N4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) a += v[k];
-        }
-        for (; sl < slices; sl++) a += src[(size_t)sl * SLICE4 + (size_t)p * POS4 + c4];
-        u4[p][col] = a;
+        for (int k = 0; k < 8; k++) a += v[k];
     }
-    __syncthreads();
-    if (t >= 64) return;
-    const float G[6][3] = {{0.25f, 0.f, 0.f},           {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-    float u[36];
-#pragma unroll
-    for (int p = 0; p < 36; p++) u[p] = reinterpret_cast<const float*>(&u4[p][0])[t];
-    float tt[3][6];                                  // tt[a][k] = sum_i G[i][a] dU[i][k]
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            float v = 0.f;
-#pragma unroll
-            for (int i = 0; i < 6; i++) v += G[i][a] * u[i * 6 + k];
-            tt[a][k] = v;
-        }
-    const size_t idx = (size_t)blockIdx.x * 64 + t;          // co * 128 + ci
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b2 = 0; b2 < 3; b2++) {
-            float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < 6; k++) v += tt[a][k] * G[k][b2];
-            dw[idx * 9 + a * 3 + b2] = v;
-        }
+    for (; sl < slices; sl++) a += src[(size_t)sl * N4];
+    reinterpret_cast<f32x4*>(dw)[i] = a;
 }
 
 }  // namespace apz
