@@ -25,8 +25,10 @@
 // output-channel groups) x both input-channel groups, four operand reads per four MFMAs, requested one step ahead.
 // Each half requests only the rows of a plane its tiles look at (9 + 8 of 15 input rows, 8 + 7 gradient rows).
 //
-// LDS: raw [3][16 planes][244] (planes padded to 976 bytes: sixteen lanes that read the same tile of sixteen planes
-// would otherwise sit on two banks), V [36][2 groups][8 tiles][16], dM [36][4 groups][8 tiles][16]; channel c of tile t
+// LDS: raw [5][16 planes][148] (the nine rows of a plane a half looks at + 16 bytes: sixteen lanes that read the same
+// tile of sixteen planes would otherwise sit on two banks; round 3 staged whole-plane slots, three buffers = two chunks
+// = 17 KB in flight per CU, and the launch's skeleton -- DMA stream + barriers, no transform, no MFMA -- took 82 of its
+// 192 us at 512 boards: latency-bound at 19 GB/s per CU), V [36][2 groups][8 tiles][16], dM [36][4 groups][8 tiles][16]; channel c of tile t
 // sits in slot c ^ 8 (t >> 1 & 1) of its group row, which makes the transform's writes and the MFMA's reads both
 // conflict-free.  157.4 KB.
 #pragma once
@@ -45,12 +47,12 @@ namespace apz {
 
 struct WgradWino2 {
     static constexpr int C = 128, CO_B = 64, CI_B = 32, BLOCKS = (C / CO_B) * (C / CI_B);   // 8 channel blocks
-    static constexpr int GPLANE = 240, RSTRIDE = 244;                   // plane as stored / as staged in LDS (floats)
+    static constexpr int GPLANE = 240, RSTRIDE = 148;                   // plane as stored / the <= 9 rows a half looks at as staged in LDS (floats)
     static constexpr int CK = 16, CHUNKS = (CI_B + CO_B) / CK;          // 6 chunks per half board: 2 input, 4 gradient
     static constexpr int RAW_FLOATS = CK * RSTRIDE;                     // 3904 per buffer
     static constexpr int OPV_FLOATS = 36 * (CI_B / 16) * 128;           // 9216
     static constexpr int OPM_FLOATS = 36 * (CO_B / 16) * 128;           // 18432
-    static constexpr int NBUF = 3;                                      // raw buffers: chunks u + 1, u + 2 are in flight while u is transformed
+    static constexpr int NBUF = 5;                                      // raw buffers: chunks u + 1 .. u + 4 are in flight while u is transformed
     static constexpr int LDS_FLOATS = NBUF * RAW_FLOATS + OPV_FLOATS + OPM_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;                    // 157 440
     static constexpr int THREADS = 512;
@@ -147,30 +149,32 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int pl = lw * 8 + i;
-                wgw_dma16(src + pl * T::GPLANE + r0 * 16 + lane * 4,
-                          lds_base + (buf * T::RAW_FLOATS + pl * T::RSTRIDE + r0 * 16) * 4);
+                wgw_dma16(src + pl * T::GPLANE + r0 * 16 + lane * 4, lds_base + (buf * T::RAW_FLOATS + pl * T::RSTRIDE) * 4);   // row r0 first
             }
         }
     };
-    if (wave >= 6) {
-        issue(0, 0);
-        issue(1, 1);
-    }
+    if (wave >= 6)
+        for (int u = 0; u < T::NBUF - 1; u++) issue(u, u);
 
     for (int u = 0; u < total; u++) {
         const int buf = u % T::NBUF;
         const int c = u % T::CHUNKS, hh = (u / T::CHUNKS) & 1;
-        // this loader's eight planes of chunk u have landed: loads retire in order, the youngest eight (chunk u + 1) may
-        // still be in flight (past the end of the stream nothing was issued: wait for everything)
+        // this loader's eight planes of chunk u have landed: loads retire in order, the youngest 24 (chunks u + 1 .. u + 3)
+        // may still be in flight (past the end of the stream nothing was issued)
         if (wave >= 6) {
-            if (u + 1 < total)
+            const int younger = min(T::NBUF - 2, total - 1 - u);
+            if (younger >= 3)
+                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (younger == 2)
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1)
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();                              // ... everybody's; chunk u - 1 (and a finished half's MFMAs) consumed
         if (wave >= 6) {
-            issue(u + 2, (u + 2) % T::NBUF);          // into the buffer chunk u - 1 has just left
+            issue(u + T::NBUF - 1, (u + T::NBUF - 1) % T::NBUF);   // into the buffer chunk u - 1 has just left
         } else if (!APZ_WGW2_NO_TRANSFORM) {
             const float* rb = raw + buf * T::RAW_FLOATS + uch * T::RSTRIDE;
             const int trow = 2 * hh + tr;             // tile row of the board (wave-uniform)
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
                 auto row6 = [&](int i, float* v) {    // patch row i (board row 4 trow - 1 + i), columns -1 .. 4
                     const int R = 4 * trow - 1 + i;
                     const bool in = R >= 0 && R <= 14;                  // (wave-uniform)
-                    const f32x4 c03 = in ? *reinterpret_cast<const f32x4*>(rb + (in ? R : 0) * 16 + 4 * ttx) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 c03 = in ? *reinterpret_cast<const f32x4*>(rb + (in ? R - (hh ? 7 : 0) : 0) * 16 + 4 * ttx) : f32x4{0.f, 0.f, 0.f, 0.f};
                     v[0] = wgw_quad_neighbour<false>(c03[3], ttx);
                     v[1] = c03[0];
                     v[2] = c03[1];
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512) void wgrad_wino2_kernel(const float* __restric
                 auto row4 = [&](int i) {              // tile row i (board row 4 trow + i), columns 0 .. 3
                     const int R = 4 * trow + i;
                     const bool in = R <= 14;
-                    return in ? *reinterpret_cast<const f32x4*>(rb + (in ? R : 0) * 16 + 4 * ttx) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    return in ? *reinterpret_cast<const f32x4*>(rb + (in ? R - (hh ? 8 : 0) : 0) * 16 + 4 * ttx) : f32x4{0.f, 0.f, 0.f, 0.f};
                 };
                 f32x4 m0, m1;
                 int i0, i1;
