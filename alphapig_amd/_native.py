@@ -116,7 +116,7 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_forward_host", "apz_forward_codes_host", "apz_forward_codes_async", "apz_submit_codes", "apz_wait", "apz_host_alloc",
                "apz_host_free", "apz_encode_planes", "apz_augment8", "apz_sample_moves_host", "apz_sample_moves_keyed_host", "apz_conv3x3_packed_size", "apz_conv3x3_pack",
                "apz_conv3x3_fwd", "apz_conv3x3_wgrad", "apz_wino_packed_size", "apz_wino_pack", "apz_wino_pack_many", "apz_wino_conv",
-               "apz_wino_conv_add", "apz_bn_fwd", "apz_bn_bwd", "apz_bn_bwd_splits", "apz_colsum", "apz_adam_step", "apz_wgrad_wino",
+               "apz_wino_conv_add", "apz_wino_conv_stats", "apz_bn_fwd", "apz_bn_fwd_stats", "apz_bn_bwd", "apz_bn_bwd_splits", "apz_colsum", "apz_adam_step", "apz_wgrad_wino",
                "apz_conv1x1_fwd", "apz_conv1x1_bwd", "apz_fc_fwd", "apz_fc_bwd", "apz_dropout", "apz_pv_loss",
                "apz_layout_convert", "apz_bias_grad", "apz_add", "apz_load_weights_dev",
                "apz_sync", "apz_stream",
@@ -242,6 +242,8 @@ def hip():
         "apz_wino_pack_many": (C.c_int, [vp, vp, C.c_int, vp, vp]),
         "apz_wino_conv": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "apz_bn_fwd": (C.c_int, [vp] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+        "apz_wino_conv_stats": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
+        "apz_bn_fwd_stats": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
         "apz_bn_bwd": (C.c_int, [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "apz_bn_bwd_splits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "apz_colsum": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),

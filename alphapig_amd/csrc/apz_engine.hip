@@ -1383,6 +1383,40 @@ int apz_wino_conv_add(apz_engine* e, const void* x_dev, const void* upk_dev, con
     return APZ_OK;
 }
 
+int apz_wino_conv_stats(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, void* y_dev,
+                        void* stats_dev, int n, void* stream) {
+    if (!e || !x_dev || !upk_dev || !y_dev || !stats_dev || n < 1) return fail(APZ_E_ARG, "bad argument");
+    if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wino_conv: 15x15 boards only");
+    if (n > WINO3_MAX_BOARDS) return fail(APZ_E_UNSUPPORTED, "wino_conv_stats: one launch (<= 16384 boards)");
+    using T = apz::Wino3;
+    EngineLock guard(e->submit_lock);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (!e->zeros256) {
+        HIP_TRY(hipMalloc((void**)&e->zeros256, 256 * sizeof(float)));
+        HIP_TRY(hipMemset(e->zeros256, 0, 256 * sizeof(float)));
+    }
+    StreamScope sc(e, stream);
+    bool& configured = e->lds_attr_set[11];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false, false, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false, false, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        configured = true;
+    }
+    const float* b = bias_dev ? (const float*)bias_dev : e->zeros256;
+    bool quarter = false;
+    const int grid = apz::wino3_grid(n, e->num_cu, e->no_quarter_trunk ? nullptr : &quarter);
+    if (quarter)
+        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false, false, true, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)upk_dev, b, (const float*)stats_dev, (float*)y_dev, n);
+    else
+        hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false, false, false, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)upk_dev, b, (const float*)stats_dev, (float*)y_dev, n);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const void* bias_dev, void* y_dev, int n, int relu,
                   int layout, void* stream) {
     return apz_wino_conv_add(e, x_dev, upk_dev, bias_dev, nullptr, y_dev, n, relu, layout, stream);
@@ -1465,8 +1499,16 @@ int bn_splits(const apz_engine* e, int n, int C, int layout) {
 int apz_bn_fwd(apz_engine* e, const void* x_dev, const void* resid_dev, const void* gamma_dev, const void* beta_dev,
                void* run_mean_dev, void* run_var_dev, void* y_dev, void* mean_dev, void* invstd_dev, int n, int C, int layout,
                int relu, float momentum, float eps, void* stream) {
+    return apz_bn_fwd_stats(e, x_dev, resid_dev, gamma_dev, beta_dev, run_mean_dev, run_var_dev, y_dev, mean_dev, invstd_dev,
+                            nullptr, n, C, layout, relu, momentum, eps, stream);
+}
+
+int apz_bn_fwd_stats(apz_engine* e, const void* x_dev, const void* resid_dev, const void* gamma_dev, const void* beta_dev,
+                     void* run_mean_dev, void* run_var_dev, void* y_dev, void* mean_dev, void* invstd_dev,
+                     const void* stats_dev, int n, int C, int layout, int relu, float momentum, float eps, void* stream) {
     if (!e || !x_dev || !beta_dev || !y_dev || !mean_dev || !invstd_dev || n < 1 || C < 1 || C > 256)
         return fail(APZ_E_ARG, "bad argument");
+    if (stats_dev && layout != APZ_LAYOUT_ROWS16) return fail(APZ_E_UNSUPPORTED, "bn_fwd_stats: padded-row layout only");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
     EngineLock guard(e->submit_lock);
@@ -1478,10 +1520,13 @@ int apz_bn_fwd(apz_engine* e, const void* x_dev, const void* resid_dev, const vo
     const apz::BnFinal fin{(float*)mean_dev, (float*)invstd_dev, (float*)run_mean_dev, (float*)run_var_dev, (double)n * H * W, eps,
                            momentum};
     if (layout == APZ_LAYOUT_ROWS16) {
-        hipLaunchKernelGGL(apz::bn_stats_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_part, n, C);
+        // statistics from the producer (apz_wino_conv_stats: one pair of sums per channel and board): no pass over x for them
+        if (!stats_dev)
+            hipLaunchKernelGGL(apz::bn_stats_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_part, n, C);
         hipLaunchKernelGGL(apz::bn_apply_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev,
-                           (const float*)resid_dev, (const float*)gamma_dev, (const float*)beta_dev, (const double*)e->bn_part,
-                           splits, fin, (float*)y_dev, n, C, relu);
+                           (const float*)resid_dev, (const float*)gamma_dev, (const float*)beta_dev,
+                           stats_dev ? (const double*)stats_dev : (const double*)e->bn_part, stats_dev ? n : splits, fin,
+                           (float*)y_dev, n, C, relu);
     } else {
         hipLaunchKernelGGL(apz::bn_stats_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_part, n, C,
                            ps, rs, H, W);

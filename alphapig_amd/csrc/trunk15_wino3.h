@@ -97,7 +97,24 @@ __device__ unsigned long long apz_wino3_stamps[4 * 8 * 8];
 // waves of a tile fetch the same fragment: L1), the input transform is unchanged (all eight waves, both boards).  The two row
 // halves of a (tile, board) meet through X as before: wave ph = 0 finishes channel sub-steps 0, 1, wave ph = 1 sub-steps 2, 3.
 // Same MFMA order per output, same transform and epilogue formulas: the same bits as the 64-channel items.
-template <bool RESID, bool RELU = true, bool QUARTER = false>
+// STATS (the training forward: no residual, no ReLU; `resid` then carries a double [128][n][2] buffer instead): the epilogue
+// also leaves, per (output channel, board), the sum and the sum of squares of the board's 225 outputs -- the per-split
+// partials of the BatchNorm that follows (conv_train.h: bn_apply adds a channel's partials itself), so that the training
+// step has no statistics pass over the tensor this kernel has just written.  A board's 225 values: a fixed fp32 tree (the
+// lane's 4x4 patch row by row, its four rows, then the sixteen lanes of the tile group by DPP adds -- in double the same
+// chain cost 7.7 us per 512-board launch, more than half of the pass it replaces); boards are added in double by the consumer.
+template <int CTRL>
+__device__ __forceinline__ float wino3_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wino3_row16_sum(float v) {
+    v = wino3_dpp_add<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+    v = wino3_dpp_add<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+    v = wino3_dpp_add<0x141>(v);      // row_half_mirror: the other quad of the 8
+    return wino3_dpp_add<0x140>(v);   // row_mirror: the other 8 of the 16
+}
+
+template <bool RESID, bool RELU = true, bool QUARTER = false, bool STATS = false>
 __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restrict__ in, const float* __restrict__ upk,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out,
@@ -161,6 +178,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t r_res =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESID ? resid : in), 0, act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, act_bytes, 0x00020000);
+    static_assert(!STATS || (!RESID && !RELU), "STATS: the training forward (bias only)");
+    const __amdgpu_buffer_rsrc_t r_st =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(STATS ? resid : in), 0, STATS ? (unsigned)n * T::C * 16u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, T::C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_u =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(upk), 0, (unsigned)(WinoPack::UPK_FLOATS * 4), 0x00020000);
@@ -580,6 +600,22 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #pragma unroll
                 for (int qp = 0; qp < 4; qp++)
                     bstore(r_out, finisher(r) ? st_out_vo : 0x80000000u, plane_so(r, qp), pv[qp]);
+                if constexpr (STATS) {
+                    float r1[4], r2[4];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        r1[a] = (y[a][0] + y[a][1]) + (y[a][2] + y[a][3]);
+                        r2[a] = (y[a][0] * y[a][0] + y[a][1] * y[a][1]) + (y[a][2] * y[a][2] + y[a][3] * y[a][3]);
+                    }
+                    if (ety == 3) r1[3] = 0.f, r2[3] = 0.f;                      // board row 15 does not exist
+                    const double d1 = (double)wino3_row16_sum((r1[0] + r1[1]) + (r1[2] + r1[3]));
+                    const double d2 = (double)wino3_row16_sum((r2[0] + r2[1]) + (r2[2] + r2[3]));
+                    const bool mine = finisher(r) && ((QUARTER ? bsel == 0 : ph == 0) || two) && (le & 15) == 0;
+                    const unsigned so = (unsigned)((cot * 16 + eq * 4 + r) * n + bd_own) * 16u;
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    const f32x4 pk = __builtin_bit_cast(f32x4, f64x2{d1, d2});
+                    bstore(r_st, mine ? so : 0x80000000u, 0u, pk);
+                }
             };
 #if APZ3_EARLY_RESID
             if constexpr (QUARTER) {

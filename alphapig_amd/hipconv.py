@@ -130,6 +130,24 @@ def conv3x3_fwd(x, weight, bias=None, layout=DENSE, relu=False, upk=None):
     return _conv3x3_run(x, weight, bias, layout, False, None, relu, upk)
 
 
+def conv3x3_fwd_stats(x, weight, bias, upk=None):
+    """The trunk shape in the padded-row layout, for a BatchNorm that follows: -> (y, stats); stats [128][n][2] float64 =
+    per (channel, board) the sum and the sum of squares of y, taken in the convolution's epilogue (bn_fwd(stats=...)
+    then makes no pass of its own over y for them)."""
+    torch = _torch()
+    L, hnd, stream = _ctx(x, ROWS16)
+    if not is_trunk_shape(weight, x, ROWS16):
+        raise ValueError("conv3x3_fwd_stats: the 128 -> 128 trunk shape in the padded-row layout")
+    n = int(x.shape[0])
+    if upk is None:
+        upk = _empty((L.apz_wino_packed_size(),), x)
+        _ck(L, L.apz_wino_pack(hnd, weight.data_ptr(), 0, upk.data_ptr(), stream))
+    y = _empty(tuple(x.shape), x)
+    stats = torch.empty((128, n, 2), dtype=torch.float64, device=x.device)
+    _ck(L, L.apz_wino_conv_stats(hnd, x.data_ptr(), upk.data_ptr(), _ptr(bias), y.data_ptr(), stats.data_ptr(), n, stream))
+    return y, stats
+
+
 def conv3x3_dgrad(dy, weight, layout=DENSE, add=None, upk=None):
     """dx = conv2d_input(dy, weight) (+ add: another gradient of the same tensor, e.g. the skip connection's).
     Needs C_in in {64, 128, 256} (the first layer's input gradient is never wanted)."""
@@ -167,15 +185,19 @@ def add_(y, x):
 
 
 # ---- BatchNorm ------------------------------------------------------------------------------------------------------
-def bn_fwd(x, gamma, beta, run_mean, run_var, resid=None, relu=True, layout=DENSE, momentum=0.1, eps=1e-3):
+def bn_fwd(x, gamma, beta, run_mean, run_var, resid=None, relu=True, layout=DENSE, momentum=0.1, eps=1e-3, stats=None):
     """y = act(batch_norm(x) (+ resid)) with batch statistics; gamma None = fixed at 1 (the reference's fix_gamma layers).
-    run_mean / run_var are updated in place (momentum = weight of the new batch value).  -> (y, mean, invstd)"""
+    run_mean / run_var are updated in place (momentum = weight of the new batch value).  -> (y, mean, invstd)
+    stats: conv3x3_fwd_stats' second result for this x."""
     L, hnd, stream = _ctx(x, layout)
     n, c = int(x.shape[0]), int(x.shape[1])
     y = _empty(tuple(x.shape), x)
     mean, invstd = _empty((c,), x), _empty((c,), x)
-    _ck(L, L.apz_bn_fwd(hnd, x.data_ptr(), _ptr(resid), _ptr(gamma), beta.data_ptr(), _ptr(run_mean), _ptr(run_var),
-                        y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), n, c, layout, int(relu), momentum, eps, stream))
+    if stats is not None and (tuple(stats.shape) != (c, n, 2) or stats.dtype != _torch().float64 or not stats.is_contiguous()):
+        raise ValueError("stats: contiguous float64 [C][n][2]")
+    _ck(L, L.apz_bn_fwd_stats(hnd, x.data_ptr(), _ptr(resid), _ptr(gamma), beta.data_ptr(), _ptr(run_mean), _ptr(run_var),
+                              y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(stats), n, c, layout, int(relu), momentum,
+                              eps, stream))
     return y, mean, invstd
 
 

@@ -138,12 +138,19 @@ class HipTrainer(object):
             for i in range(1, self.n_blocks + 1):
                 A, B = "A%d" % i, "B%d" % i
                 ua, ub = (upk[2 * i - 2, 0], upk[2 * i - 1, 0]) if upk is not None else (None, None)
-                ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay, upk=ua)
+                sa = sb = None
+                if upk is not None:     # the Winograd kernel's epilogue leaves the BatchNorm's per-board sums: no statistics pass
+                    ya, sa = o.conv3x3_fwd_stats(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], upk=ua)
+                else:
+                    ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay)
                 ha, ma, ia = o.bn_fwd(ya, p["bn" + A + "_gamma"], p["bn" + A + "_beta"], p["bn" + A + "_moving_mean"],
-                                      p["bn" + A + "_moving_var"], None, True, lay, 1.0 - BN_MOMENTUM, BN_EPS)
-                yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay, upk=ub)
+                                      p["bn" + A + "_moving_var"], None, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sa)
+                if upk is not None:
+                    yb, sb = o.conv3x3_fwd_stats(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], upk=ub)
+                else:
+                    yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay)
                 out, mb, ib = o.bn_fwd(yb, p["bn" + B + "_gamma"], p["bn" + B + "_beta"], p["bn" + B + "_moving_mean"],
-                                       p["bn" + B + "_moving_var"], x, True, lay, 1.0 - BN_MOMENTUM, BN_EPS)
+                                       p["bn" + B + "_moving_var"], x, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sb)
                 tape["blocks"].append((x, ya, ha, ma, ia, yb, out, mb, ib))
                 x = out
         else:

@@ -167,6 +167,16 @@ int apz_wino_conv(apz_engine *e, const void *x_dev, const void *upk_dev, const v
  * convolution meets the skip gradient inside the kernel's epilogue (trunk15_wino3.h) */
 int apz_wino_conv_add(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev,
                       const void *resid_dev, void *y_dev, int n, int relu, int layout, void *stream);
+/* The training forward of a trunk layer (policy_value_net_mxnet.py:41-56: Convolution, then BatchNorm): y = conv(x, upk)
+ * + bias in the padded-row layout, and stats_dev [128][n][2] doubles = per (channel, board) the sum and the sum of
+ * squares of the board's 225 outputs, taken in the kernel's epilogue.  apz_bn_fwd_stats = apz_bn_fwd that takes its
+ * batch statistics from such a buffer (stats_dev NULL: computes them itself) instead of a pass over x. */
+int apz_wino_conv_stats(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev, void *y_dev,
+                        void *stats_dev, int n, void *stream);
+int apz_bn_fwd_stats(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
+                     const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
+                     void *invstd_dev, const void *stats_dev, int n, int C, int layout, int relu, float momentum,
+                     float eps, void *stream);
 /* Training-mode BatchNorm (+ residual) (+ ReLU), the reference's BatchNorm(eps = 1e-3) between the trunk's
  * convolutions (policy_value_net_mxnet.py:41-102), over n x C planes in `layout`:
  *   apz_bn_fwd  y = act((x - mean_c) * invstd_c * gamma_c + beta_c (+ resid)); batch statistics (biased

@@ -168,6 +168,36 @@ def test_bn_forward_backward(layout, relu, resid, gamma, c):
     assert close(rmc, rm64, 1e-5) and close(rvc, rv64, 1e-5)
 
 
+@pytest.mark.parametrize("n", [1, 7, 64, 128, 131, 512])
+def test_trunk_conv_leaves_the_batchnorm_statistics(n):
+    """conv3x3_fwd_stats: the same y as conv3x3_fwd bit for bit (item = board pair x 32 or 64 channels, odd batches), and per
+    (channel, board) the sum / sum of squares of the board's 225 outputs; BatchNorm from them == BatchNorm with its own
+    statistics pass up to the rounding of the sums (policy_value_net_mxnet.py:41-56)."""
+    from alphapig_amd import hipconv
+    g = torch.Generator().manual_seed(100 + n)
+    x = pad16(torch.randn(n, 128, 15, 15, generator=g)).cuda()
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34).cuda()
+    b = torch.randn(128, generator=g).cuda()
+    be = (torch.randn(128, generator=g) * 0.2).cuda()
+    y0 = hipconv.conv3x3_fwd(x, w, b, hipconv.ROWS16)
+    y, st = hipconv.conv3x3_fwd_stats(x, w, b)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    y64 = y[..., :15].double()
+    s1, s2 = y64.sum(dim=(2, 3)).t(), (y64 * y64).sum(dim=(2, 3)).t()          # [C][n]
+    assert float((st[..., 0] - s1).abs().max()) < 1e-5 * float(y64.abs().sum(dim=(2, 3)).max())
+    assert float((st[..., 1] - s2).abs().max()) < 1e-5 * float(s2.max())
+    a0, m0, i0 = hipconv.bn_fwd(y, None, be, None, None, None, True, hipconv.ROWS16, 0.1, 1e-3)
+    a1, m1, i1 = hipconv.bn_fwd(y, None, be, None, None, None, True, hipconv.ROWS16, 0.1, 1e-3, stats=st)
+    torch.cuda.synchronize()
+    assert float((m0 - m1).abs().max()) < 1e-6 * float(m0.abs().max()) + 1e-7
+    assert float(((i0 - i1) / i0).abs().max()) < 1e-5
+    assert float((a0 - a1).abs().max()) < 1e-4 * float(a0.abs().max())
+    y2, st2 = hipconv.conv3x3_fwd_stats(x, w, b)                                   # no atomics: the same bits again
+    torch.cuda.synchronize()
+    assert torch.equal(st, st2)
+
+
 @pytest.mark.parametrize("n,layout,c", [(130, 1, 128), (515, 1, 128), (300, 0, 4), (300, 0, 128)])
 def test_bn_batch_splits(n, layout, c):
     """... at batch sizes that give every channel several batch splits (padded rows: four boards per trip and split): the
