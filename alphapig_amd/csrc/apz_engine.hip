@@ -21,7 +21,7 @@
 #include "trunk15_wino3s.h"
 #include "trunk15_wino3b.h"
 #include "conv8_small.h"
-#include "wgrad_wino2.h"
+#include "wgrad_wino3.h"
 #include "sampler.h"
 #include "conv_train.h"
 #include "heads_train.h"
@@ -1593,14 +1593,15 @@ int apz_colsum(apz_engine* e, const void* in_dev, void* out_dev, int rows, int c
 int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, void* stream) {
     if (!e || !x_dev || !dy_dev || !dw_dev || n < 1) return fail(APZ_E_ARG, "bad argument");
     if (e->cfg.height != 15 || e->cfg.width != 15) return fail(APZ_E_UNSUPPORTED, "wgrad_wino: 15x15 boards only");
+    if (n > 32768) return fail(APZ_E_UNSUPPORTED, "wgrad_wino: at most 32768 boards per call (32-bit buffer offsets)");
     using T = apz::WgradWino;
+    using T3 = apz::WgradWino3;
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    // Decomposition by channel blocks (csrc/wgrad_wino2.h: 8 blocks x slices = one workgroup per CU); the workgroups of a
+    // Decomposition by channel blocks (csrc/wgrad_wino3.h: 16 blocks x slices = one workgroup per CU); the workgroups of a
     // slice sit on one XCD (see the kernel)
-    using T2 = apz::WgradWino2;
-    const int spx = std::max(1, std::min((n + 7) / 8, e->num_cu / (8 * T2::BLOCKS)));
+    const int spx = std::max(1, std::min((n + 7) / 8, e->num_cu / (8 * T3::BLOCKS)));
     const int slices = 8 * spx;
     if (slices > e->wgw_slices) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1609,13 +1610,12 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
         HIP_TRY(hipMalloc((void**)&e->wgw_scratch, (size_t)slices * T::SCRATCH_FLOATS_PER_SLICE * sizeof(float)));
         e->wgw_slices = slices;
     }
-    bool& attr2 = e->lds_attr_set[10];
-    if (!attr2) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T2::LDS_BYTES));
-        attr2 = true;
+    bool& attr = e->lds_attr_set[10];
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+        attr = true;
     }
-    hipLaunchKernelGGL(apz::wgrad_wino2_kernel, dim3(T2::BLOCKS * slices), dim3(T2::THREADS), T2::LDS_BYTES, e->stream,
+    hipLaunchKernelGGL(apz::wgrad_wino3_kernel, dim3(T3::BLOCKS * slices), dim3(T3::THREADS), T3::LDS_BYTES, e->stream,
                        (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
     hipLaunchKernelGGL(apz::wgrad_wino_finish_kernel, dim3(128 * 128 * 9 / 4 / 256), dim3(256), 0, e->stream,
                        (const float*)e->wgw_scratch, slices, (float*)dw_dev);

@@ -3,7 +3,7 @@
 // layers (as one fp32-MFMA GEMM kernel), Dropout(0.5), and the loss
 //   mean((z - tanh(u))^2) + mean(-sum(pi * log softmax(logits)))   with the entropy monitor mean(sum(-p log p)),
 // forward and backward.  gfx950 only.  (3x3 convolutions: conv3x3_mfma.h / trunk15_wino3.h / conv_train.h /
-// wgrad_wino2.h; BatchNorm and Adam: conv_train.h.)
+// wgrad_wino3.h; BatchNorm and Adam: conv_train.h.)
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,14 +1,18 @@
-// Weight gradient of the trunk convolution (128 -> 128, 15x15) through the Winograd F(4x4,3x3) domain, third form:
-// 32 x 32 channel blocks, one complete transform per thread.  gfx950.
+// Weight gradient of the trunk convolution (128 -> 128, 15x15) through the Winograd F(4x4,3x3) domain.  gfx950.
 //
-// The arithmetic is wgrad_wino2.h's (dU[pos][co][ci] = sum over boards and tiles of dM[pos][co][tile] V[pos][ci][tile],
-// dg = G^T dU G; same transform formulas, same accumulation order per accumulator).  What changed is the decomposition.
-// wgrad_wino2_kernel gives a workgroup a 64 x 32 channel block: 144 accumulator registers per wave, which leaves a wave
-// room for a THIRD of a (plane, tile) transform at a time (two of the six rows: three "roles"), so every patch is read
-// and its first stage recomputed three times (10 800 vector instructions per wave where ~3 600 would do), six of the
-// eight waves transform one 16-plane chunk per barrier (14 barriers per board, one dependent chain per thread between
-// them) and the phases add up: at 512 boards 82 us skeleton-bound transform phases + 67 us of MFMAs + epilogue = 187 us,
-// matrix pipe busy 0.35 (profiles/r03_train_bench.md, profiles/r04_wgrad_ablation.log).
+// Forward (trunk15_wino3.h): Y = A^T [ sum_ci U (.) V ] A with U = G g G^T, V = B^T d B.  Hence
+//   dU[pos][co][ci] = sum over boards and tiles of dM[pos][co][tile] * V[pos][ci][tile],  dM = A dY A^T (6x6 from 4x4),
+//   dg[co][ci]      = G^T dU G                                                             (3x3 from 6x6)
+// i.e. 36 independent [128 x K] x [K x 128] products with K = 16 tiles per board: 9 216 fp32 MFMAs per board instead of the
+// 32 832 of the direct form (conv3x3_wgrad_kernel).  Every workgroup applies G^T . G to its own partial dU (epilogue) and
+// writes a partial dg of its batch slice to a scratch tensor; wgrad_wino_finish_kernel adds the slices.
+//
+// History (profiles/r04_wgrad_wino3.md).  Round 2: a workgroup = three positions x all channels (every plane read twelve
+// times).  Rounds 2 - 4, `wgrad_wino2_kernel` (in the git history): 64 x 32 channel blocks, 144 accumulator registers per
+// wave, which left a wave room for a THIRD of a (plane, tile) transform at a time (two of the six rows: three "roles"), so
+// every patch was read and its first stage recomputed three times; planes staged in LDS by LDS-DMA (16 bytes per clock and
+// CU: 64 cycles per plane request); six of eight waves transformed one 16-plane chunk per barrier (14 barriers per board)
+// and the phases added up: 187 us per 512 boards, matrix pipe busy 0.35.
 //
 // Here a workgroup (512 threads, one per CU) owns 32 output x 32 input channels with all 36 positions: 72 accumulator
 // registers per wave (wave = nine positions x one of the two output-channel groups x both input-channel groups).  A half
@@ -18,16 +22,19 @@
 // (V = B^T d B), waves 4..7 its 32 gradient planes (dM = A dY A^T).  The operand arrays are double-buffered, so there is
 // ONE barrier per half board, and a wave that is done with a half's MFMAs goes straight on to the next half's transform
 // while the SIMD's other wave still feeds the matrix pipe.  Input planes are read by four workgroups instead of two (all
-// of a slice's sixteen blocks sit on one XCD: L2 hits).
+// of a slice's sixteen blocks sit on one XCD: L2 hits).  145 us per 512 boards (0.42 of the fp32 matrix peak), 40 us at 128.
+// What bounds it now: the fp32 matrix instructions run on the vector unit's FMA lanes, so a half board costs its 2 304
+// cycles of MFMAs PLUS ~1 800 cycles of transform instructions (373 per SIMD and half at ~4.8 cycles each), + ~700 of
+// barrier and loop ends; packed two-wide transform arithmetic and buffer loads with hardware zero fill were measured and
+// changed nothing (146.7 / 149.7 us).
 //
 // LDS: two operand sets of V [36][2 groups][8 tiles][16] + dM [36][2 groups][8 tiles][16]; channel c of tile t sits in slot
 // (c + 4 (t >> 1)) & 15 of its (position, group, tile) row: the transform's stores (lane = plane x tile) and the MFMA's
-// loads (lane = tile x channel) are both conflict-free.  147.5 KB; the epilogue (G^T dU G through LDS, as in
-// wgrad_wino2.h) takes 152 KB.
+// loads (lane = tile x channel) are both conflict-free.  147.5 KB; the epilogue (G^T dU G through LDS) takes 152 KB.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "wgrad_wino2.h"
+#include "wino_common.h"
 
 #ifndef APZ_WGW3_NO_TRANSFORM
 #define APZ_WGW3_NO_TRANSFORM 0   /* measurement builds: skip the transforms / the MFMA phase */
@@ -37,6 +44,18 @@
 #endif
 
 namespace apz {
+
+// partial weight gradient of one batch slice: [128 co][128 ci][3][3]
+struct WgradWino {
+    static constexpr size_t SCRATCH_FLOATS_PER_SLICE = (size_t)128 * 128 * 9;
+};
+
+// lane k of every quad takes `v` of lane k-1 (DOWN) / k+1 (UP); the quad's ends get 0
+template <bool UP>
+__device__ __forceinline__ float wgw_quad_neighbour(float v, int k) {
+    const int moved = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), UP ? 0xf9 : 0x90, 0xf, 0xf, false);   // quad_perm [1,2,3,3] / [0,0,1,2]
+    return k == (UP ? 3 : 0) ? 0.f : __builtin_bit_cast(float, moved);
+}
 
 #ifdef APZ_WGW3_STAMPS
 // measurement builds: cycles per wave of workgroup 0 in (0) loop overhead, (2) transform, (3) barrier, (4) MFMA phase,
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(512) void wgrad_wino3_kernel(const float* __restric
                     xr[i][5] = wgw_quad_neighbour<true>(c03[0], ttx);
                 }
                 prefetch(u + 1);                      // in flight during the barrier and this half's MFMAs
-                float y[6][6];                        // y = B^T d (the expressions of wgrad_wino2.h's three roles)
+                float y[6][6];                        // y = B^T d (rows 0 / 5, 1 / 2, 3 / 4 share their partial sums)
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     y[0][k] = __builtin_fmaf(4.f, xr[0][k], __builtin_fmaf(-5.f, xr[2][k], xr[4][k]));
@@ -288,6 +307,26 @@ __global__ __launch_bounds__(512) void wgrad_wino3_kernel(const float* __restric
     if (blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 6; k++) apz_wgw3_stamps[wave][k] = st_acc[k];
 #endif
+}
+
+// dw[co][ci][3][3] = sum over the slices' partials, in slice order (16-byte accesses; 0.59 MB per slice)
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ scratch, int slices,
+                                                                float* __restrict__ dw) {
+    constexpr size_t N4 = WgradWino::SCRATCH_FLOATS_PER_SLICE / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N4) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(scratch) + i;
+    f32x4 a = src[0];
+    int sl = 1;
+    for (; sl + 7 < slices; sl += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[(size_t)(sl + k) * N4];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a += v[k];
+    }
+    for (; sl < slices; sl++) a += src[(size_t)sl * N4];
+    reinterpret_cast<f32x4*>(dw)[i] = a;
 }
 
 }  // namespace apz

@@ -1,4 +1,4 @@
-// Shared pieces of the Winograd F(4x4,3x3) trunk kernels (trunk15_wino3.h, wgrad_wino2.h) for gfx950: vector types,
+// Shared pieces of the Winograd F(4x4,3x3) trunk kernels (trunk15_wino3.h, wgrad_wino3.h) for gfx950: vector types,
 // the packed FMA, the wavefront-scope LDS fence and the packed-weight geometry.
 #pragma once
 #include <hip/hip_runtime.h>
