@@ -196,7 +196,7 @@ int apz_bn_fwd_stats(apz_engine *e, const void *x_dev, const void *resid_dev, co
 int apz_bn_fwd(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
                const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
                void *invstd_dev, int n, int C, int layout, int relu, float momentum, float eps, void *stream);
-/* Weight gradient of the trunk shape (128 -> 128, 15x15) through the Winograd domain (csrc/wgrad_wino2.h; 3.6x fewer
+/* Weight gradient of the trunk shape (128 -> 128, 15x15) through the Winograd domain (csrc/wgrad_wino3.h; 3.6x fewer
  * MFMAs than apz_conv3x3_wgrad): x_dev / dy_dev in the padded-row layout [n][128][15][16], dw_dev [128][128][3][3]
  * overwritten. */
 int apz_wgrad_wino(apz_engine *e, const void *x_dev, const void *dy_dev, void *dw_dev, int n, void *stream);
