@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
         for (int t = 0; t < 9; t++) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const float* arow = yt + j * G::YPS + q;                 // A: co = j (+16 per tile), pixel = 4s + q
-    const float* brow = xt + (wave * 16 + j) * G::XPS;       // B: ci = wave*16 + j
+    const float* brow = xt + (wave * 16 + j) * G::XPS;       // B: ci = wave*16 + j (by_pixels: ci = j, below)
 
     f32x4 px[XV], py[YV];
     auto fetch = [&](int b) {               // global -> registers (16-byte pieces; tiles are 16-B aligned)
@@ -592,13 +592,36 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
         }
     };
 
+    // <= 16 input channels (the stem: 9 planes): one wave would do all of the workgroup's MFMAs (188 us per 512 boards for
+    // a layer of 2.4 GFLOP) -- the four waves then split the k-steps (pixels) of channel tile 0 instead of the channel
+    // tiles, and their partial sums meet in the epilogue's staging area
+    const bool by_pixels = nci <= 16;
+    if (by_pixels) brow = xt + j * G::XPS;
     fetch(blockIdx.z);
     for (int b = blockIdx.z; b < n; b += gridDim.z) {
         __syncthreads();                     // previous board's tiles fully consumed (and the zero fill done)
         scatter();
         __syncthreads();
         fetch(b + gridDim.z);                // in flight during the MFMA loop below
-        if (wave * 16 < nci) {               // wave-uniform: this wave's 16 input channels exist
+        if (by_pixels) {
+            for (int s = wave; s < G::KSTEPS; s += 4) {
+                float a[COT];
+#pragma unroll
+                for (int c = 0; c < COT; c++) a[c] = arow[c * 16 * G::YPS + 4 * s];
+                const int p = 4 * s + q, yy = p / WP, xx = p - yy * WP;
+                const int yc = yy < H ? yy : H - 1;          // tail lanes: dY there is 0, stay in bounds
+                const float* bp = brow + yc * G::RS + xx;
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const float bv = bp[ky * G::RS + kx];
+#pragma unroll
+                        for (int c = 0; c < COT; c++)
+                            acc[c][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bv, acc[c][ky * 3 + kx], 0, 0, 0);
+                    }
+            }
+        } else if (wave * 16 < nci) {        // wave-uniform: this wave's 16 input channels exist
             int yy = 0, xx = q;              // pixel 4s + q as (row, col), advanced incrementally (W >= 4)
 #pragma unroll 3
             for (int s = 0; s < G::KSTEPS; s++) {
@@ -628,7 +651,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     constexpr int ROW = 64 * 9 + 1;
     static_assert(32 * ROW <= G::LDS_FLOATS, "epilogue staging fits the tile memory");
     float* st = sm;
-    if (wave * 16 < nci) {
+    if (by_pixels) {                         // the four waves' partial sums of channel tile 0, added in wave order
+        for (int w = 0; w < 4; w++) {
+            if (wave == w) {
+#pragma unroll
+                for (int c = 0; c < COT; c++)
+#pragma unroll
+                    for (int t = 0; t < 9; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float* d = st + (c * 16 + q * 4 + r) * ROW + j * 9 + t;
+                            *d = w ? *d + acc[c][t][r] : acc[c][t][r];
+                        }
+            }
+            __syncthreads();
+        }
+    } else if (wave * 16 < nci) {
 #pragma unroll
         for (int c = 0; c < COT; c++)
 #pragma unroll
