@@ -243,8 +243,8 @@ def hip():
         "apz_wino_conv": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "apz_bn_fwd": (C.c_int, [vp] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
         "apz_wino_conv_stats": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
-        "apz_bn_fwd_stats": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
-        "apz_bn_bwd": (C.c_int, [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_bn_fwd_stats": (C.c_int, [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+        "apz_bn_bwd": (C.c_int, [vp] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "apz_bn_bwd_splits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "apz_colsum": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
         "apz_wgrad_wino": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),

@@ -1500,15 +1500,16 @@ int apz_bn_fwd(apz_engine* e, const void* x_dev, const void* resid_dev, const vo
                void* run_mean_dev, void* run_var_dev, void* y_dev, void* mean_dev, void* invstd_dev, int n, int C, int layout,
                int relu, float momentum, float eps, void* stream) {
     return apz_bn_fwd_stats(e, x_dev, resid_dev, gamma_dev, beta_dev, run_mean_dev, run_var_dev, y_dev, mean_dev, invstd_dev,
-                            nullptr, n, C, layout, relu, momentum, eps, stream);
+                            nullptr, nullptr, n, C, layout, relu, momentum, eps, stream);
 }
 
 int apz_bn_fwd_stats(apz_engine* e, const void* x_dev, const void* resid_dev, const void* gamma_dev, const void* beta_dev,
                      void* run_mean_dev, void* run_var_dev, void* y_dev, void* mean_dev, void* invstd_dev,
-                     const void* stats_dev, int n, int C, int layout, int relu, float momentum, float eps, void* stream) {
+                     const void* stats_dev, void* mask_dev, int n, int C, int layout, int relu, float momentum, float eps,
+                     void* stream) {
     if (!e || !x_dev || !beta_dev || !y_dev || !mean_dev || !invstd_dev || n < 1 || C < 1 || C > 256)
         return fail(APZ_E_ARG, "bad argument");
-    if (stats_dev && layout != APZ_LAYOUT_ROWS16) return fail(APZ_E_UNSUPPORTED, "bn_fwd_stats: padded-row layout only");
+    if ((stats_dev || mask_dev) && layout != APZ_LAYOUT_ROWS16) return fail(APZ_E_UNSUPPORTED, "bn_fwd_stats: padded-row layout only");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
     EngineLock guard(e->submit_lock);
@@ -1526,7 +1527,7 @@ int apz_bn_fwd_stats(apz_engine* e, const void* x_dev, const void* resid_dev, co
         hipLaunchKernelGGL(apz::bn_apply_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev,
                            (const float*)resid_dev, (const float*)gamma_dev, (const float*)beta_dev,
                            stats_dev ? (const double*)stats_dev : (const double*)e->bn_part, stats_dev ? n : splits, fin,
-                           (float*)y_dev, n, C, relu);
+                           (float*)y_dev, (unsigned char*)mask_dev, n, C, relu);
     } else {
         hipLaunchKernelGGL(apz::bn_stats_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)x_dev, e->bn_part, n, C,
                            ps, rs, H, W);
@@ -1543,11 +1544,11 @@ int apz_bn_bwd_splits(apz_engine* e, int n, int C, int layout) {
     return bn_splits(e, n, C, layout);
 }
 
-int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void* out_dev, const void* gamma_dev,
-               const void* mean_dev, const void* invstd_dev, void* dx_dev, void* dres_dev, void* dgamma_dev, void* dbeta_dev,
-               void* dxsum_dev, int dxsum_ld, int n, int C, int layout, int relu, void* stream) {
-    if (!e || !dy_dev || !x_dev || !mean_dev || !invstd_dev || !dx_dev || n < 1 || C < 1 || C > 256 || (relu && !out_dev) ||
-        (dxsum_dev && dxsum_ld < C))
+int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void* out_dev, const void* mask_dev,
+               const void* gamma_dev, const void* mean_dev, const void* invstd_dev, void* dx_dev, void* dres_dev, void* dgamma_dev,
+               void* dbeta_dev, void* dxsum_dev, int dxsum_ld, int n, int C, int layout, int relu, void* stream) {
+    if (!e || !dy_dev || !x_dev || !mean_dev || !invstd_dev || !dx_dev || n < 1 || C < 1 || C > 256 ||
+        (relu && !out_dev && !mask_dev) || (dxsum_dev && dxsum_ld < C) || (mask_dev && layout != APZ_LAYOUT_ROWS16))
         return fail(APZ_E_ARG, "bad argument");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
@@ -1560,11 +1561,12 @@ int apz_bn_bwd(apz_engine* e, const void* dy_dev, const void* x_dev, const void*
     if (layout == APZ_LAYOUT_ROWS16) {
         hipLaunchKernelGGL(apz::bn_bwd_reduce_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
                            (const float*)x_dev, (const float*)out_dev, (const float*)mean_dev, (const float*)invstd_dev,
-                           e->bn_part, n, C, relu);
+                           e->bn_part, (const unsigned char*)mask_dev, n, C, relu);
         hipLaunchKernelGGL(apz::bn_bwd_apply_r16_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
                            (const float*)x_dev, (const float*)out_dev, (const float*)gamma_dev, (const float*)mean_dev,
                            (const float*)invstd_dev, (const double*)e->bn_part, splits, (float*)dx_dev, (float*)dres_dev,
-                           (float*)dgamma_dev, (float*)dbeta_dev, (float*)dxsum_dev, dxsum_ld, n, C, relu, (double)n * H * W);
+                           (float*)dgamma_dev, (float*)dbeta_dev, (float*)dxsum_dev, dxsum_ld, (const unsigned char*)mask_dev, n, C,
+                           relu, (double)n * H * W);
     } else {
         hipLaunchKernelGGL(apz::bn_bwd_reduce_kernel, dim3(C, splits), dim3(256), 0, e->stream, (const float*)dy_dev,
                            (const float*)x_dev, (const float*)out_dev, (const float*)mean_dev, (const float*)invstd_dev,

@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) void bn_stats_r16_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bn_apply_r16_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const double* __restrict__ part, int psplits, BnFinal fin,
-                                                           float* __restrict__ y, int n, int C, int relu) {
+                                                           float* __restrict__ y, unsigned char* __restrict__ mask, int n, int C,
+                                                           int relu) {
     __shared__ double sh[4];
     const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;
     float m, is;
@@ -403,13 +404,16 @@ __global__ __launch_bounds__(256) void bn_apply_r16_kernel(const float* __restri
         }
         if ((k & 3) == 3) a[3] = 0.f;            // the pad column (60 float4 per plane: 4 per row)
         reinterpret_cast<f32x4*>(y)[o] = a;
+        // the ReLU decisions of these four elements for the backward pass: one byte per 16 bytes of y (bn_bwd_* then read
+        // 3.9 MB instead of the 63 MB output tensor per 512-board layer, twice)
+        if (mask) mask[o] = (unsigned char)((a[0] > 0.f) | ((a[1] > 0.f) << 1) | ((a[2] > 0.f) << 2) | ((a[3] > 0.f) << 3));
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_r16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ out, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, double* __restrict__ part,
-                                                                int n, int C, int relu) {
+                                                                const unsigned char* __restrict__ mask, int n, int C, int relu) {
     __shared__ double sh[4];
     const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;
     const float m = mean[c], is = invstd[c];
@@ -419,7 +423,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_r16_kernel(const float* __r
             const size_t o = ((size_t)b * C + c) * 60 + k;
             f32x4 g = reinterpret_cast<const f32x4*>(dy)[o];
             const f32x4 xv = reinterpret_cast<const f32x4*>(x)[o];
-            if (relu) {
+            if (relu && mask) {
+                const unsigned bits = mask[o];
+#pragma unroll
+                for (int e = 0; e < 4; e++) g[e] = (bits >> e) & 1u ? g[e] : 0.f;
+            } else if (relu) {
                 const f32x4 ov = reinterpret_cast<const f32x4*>(out)[o];
 #pragma unroll
                 for (int e = 0; e < 4; e++) g[e] = ov[e] > 0.f ? g[e] : 0.f;
@@ -447,7 +455,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_r16_kernel(const float* __re
                                                                const double* __restrict__ part, int psplits,
                                                                float* __restrict__ dx, float* __restrict__ dres,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ dxsum, int dxsum_ld, int n, int C, int relu,
+                                                               float* __restrict__ dxsum, int dxsum_ld,
+                                                               const unsigned char* __restrict__ mask, int n, int C, int relu,
                                                                double M) {
     __shared__ double sh[4];
     const int c = blockIdx.x, t = threadIdx.x, sub = t / 60, k = t - sub * 60;
@@ -465,7 +474,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_r16_kernel(const float* __re
             const size_t o = ((size_t)b * C + c) * 60 + k;
             f32x4 g = reinterpret_cast<const f32x4*>(dy)[o];
             const f32x4 xv = reinterpret_cast<const f32x4*>(x)[o];
-            if (relu) {
+            if (relu && mask) {
+                const unsigned bits = mask[o];
+#pragma unroll
+                for (int e = 0; e < 4; e++) g[e] = (bits >> e) & 1u ? g[e] : 0.f;
+            } else if (relu) {
                 const f32x4 ov = reinterpret_cast<const f32x4*>(out)[o];
 #pragma unroll
                 for (int e = 0; e < 4; e++) g[e] = ov[e] > 0.f ? g[e] : 0.f;

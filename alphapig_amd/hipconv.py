@@ -185,24 +185,28 @@ def add_(y, x):
 
 
 # ---- BatchNorm ------------------------------------------------------------------------------------------------------
-def bn_fwd(x, gamma, beta, run_mean, run_var, resid=None, relu=True, layout=DENSE, momentum=0.1, eps=1e-3, stats=None):
+def bn_fwd(x, gamma, beta, run_mean, run_var, resid=None, relu=True, layout=DENSE, momentum=0.1, eps=1e-3, stats=None,
+           want_mask=False):
     """y = act(batch_norm(x) (+ resid)) with batch statistics; gamma None = fixed at 1 (the reference's fix_gamma layers).
     run_mean / run_var are updated in place (momentum = weight of the new batch value).  -> (y, mean, invstd)
-    stats: conv3x3_fwd_stats' second result for this x."""
+    stats: conv3x3_fwd_stats' second result for this x.  want_mask (padded rows): -> (y, mean, invstd, mask), mask = the
+    ReLU decisions as uint8 [n][C][60] (4 bits per byte), for bn_bwd(mask=...)."""
     L, hnd, stream = _ctx(x, layout)
     n, c = int(x.shape[0]), int(x.shape[1])
     y = _empty(tuple(x.shape), x)
     mean, invstd = _empty((c,), x), _empty((c,), x)
     if stats is not None and (tuple(stats.shape) != (c, n, 2) or stats.dtype != _torch().float64 or not stats.is_contiguous()):
         raise ValueError("stats: contiguous float64 [C][n][2]")
+    mask = _torch().empty((n, c, 60), dtype=_torch().uint8, device=x.device) if want_mask else None
     _ck(L, L.apz_bn_fwd_stats(hnd, x.data_ptr(), _ptr(resid), _ptr(gamma), beta.data_ptr(), _ptr(run_mean), _ptr(run_var),
-                              y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(stats), n, c, layout, int(relu), momentum,
-                              eps, stream))
-    return y, mean, invstd
+                              y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(stats), _ptr(mask), n, c, layout, int(relu),
+                              momentum, eps, stream))
+    return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)
 
 
-def bn_bwd(dy, x, y, gamma, mean, invstd, relu=True, want_dres=False, layout=DENSE, dxsum=None):
-    """-> (dx, dres or None, dgamma, dbeta); y is the forward output (the ReLU mask).
+def bn_bwd(dy, x, y, gamma, mean, invstd, relu=True, want_dres=False, layout=DENSE, dxsum=None, mask=None):
+    """-> (dx, dres or None, dgamma, dbeta); y is the forward output (the ReLU mask) -- or None when mask (bn_fwd's
+    want_mask result) carries the ReLU decisions.
     dxsum: a [bn_bwd_splits(x, layout)][C] view (row stride >= C) of a float32 matrix that receives the per-split column
     sums of dx -- colsum() of it is the bias gradient of the convolution in front (bias_parts() hands such views out)."""
     L, hnd, stream = _ctx(x, layout)
@@ -215,7 +219,9 @@ def bn_bwd(dy, x, y, gamma, mean, invstd, relu=True, want_dres=False, layout=DEN
         if tuple(dxsum.shape) != (bn_bwd_splits(x, layout), c) or dxsum.stride(1) != 1:
             raise ValueError("dxsum: a [splits][C] view with unit column stride")
         ld = int(dxsum.stride(0))
-    _ck(L, L.apz_bn_bwd(hnd, dy.data_ptr(), x.data_ptr(), y.data_ptr(), _ptr(gamma), mean.data_ptr(), invstd.data_ptr(),
+    if mask is not None and (tuple(mask.shape) != (n, c, 60) or mask.dtype != _torch().uint8 or not mask.is_contiguous()):
+        raise ValueError("mask: contiguous uint8 [n][C][60]")
+    _ck(L, L.apz_bn_bwd(hnd, dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(mask), _ptr(gamma), mean.data_ptr(), invstd.data_ptr(),
                         dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dxsum), ld, n, c, layout, int(relu),
                         stream))
     return dx, dres, dgamma, dbeta

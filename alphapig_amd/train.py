@@ -143,15 +143,18 @@ class HipTrainer(object):
                     ya, sa = o.conv3x3_fwd_stats(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], upk=ua)
                 else:
                     ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay)
-                ha, ma, ia = o.bn_fwd(ya, p["bn" + A + "_gamma"], p["bn" + A + "_beta"], p["bn" + A + "_moving_mean"],
-                                      p["bn" + A + "_moving_var"], None, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sa)
+                wm = self.rows16        # padded rows: the ReLU decisions as a byte per four elements for the backward pass
+                ha, ma, ia, *ka = o.bn_fwd(ya, p["bn" + A + "_gamma"], p["bn" + A + "_beta"], p["bn" + A + "_moving_mean"],
+                                           p["bn" + A + "_moving_var"], None, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sa,
+                                           want_mask=wm)
                 if upk is not None:
                     yb, sb = o.conv3x3_fwd_stats(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], upk=ub)
                 else:
                     yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay)
-                out, mb, ib = o.bn_fwd(yb, p["bn" + B + "_gamma"], p["bn" + B + "_beta"], p["bn" + B + "_moving_mean"],
-                                       p["bn" + B + "_moving_var"], x, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sb)
-                tape["blocks"].append((x, ya, ha, ma, ia, yb, out, mb, ib))
+                out, mb, ib, *kb = o.bn_fwd(yb, p["bn" + B + "_gamma"], p["bn" + B + "_beta"], p["bn" + B + "_moving_mean"],
+                                            p["bn" + B + "_moving_var"], x, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sb,
+                                            want_mask=wm)
+                tape["blocks"].append((x, ya, ha, ma, ia, yb, out, mb, ib, ka[0] if ka else None, kb[0] if kb else None))
                 x = out
         else:
             lay = o.DENSE
@@ -194,15 +197,15 @@ class HipTrainer(object):
             parts = o._empty((o.bn_bwd_splits(tape["blocks"][0][1], lay), 2 * nb * nf), dx)
             for i in range(nb, 0, -1):
                 A, B = "A%d" % i, "B%d" % i
-                x, ya, ha, ma, ia, yb, out, mb, ib = tape["blocks"][i - 1]
+                x, ya, ha, ma, ia, yb, out, mb, ib, ka, kb = tape["blocks"][i - 1]
                 ua, ub = (upk[2 * i - 2, 1], upk[2 * i - 1, 1]) if upk is not None else (None, None)
                 ca, cb = (2 * i - 2) * nf, (2 * i - 1) * nf
                 dyb, dskip, g["bn" + B + "_gamma"], g["bn" + B + "_beta"] = o.bn_bwd(dx, yb, out, p["bn" + B + "_gamma"], mb, ib,
-                                                                                    True, True, lay, dxsum=parts[:, cb:cb + nf])
+                                                                                    True, True, lay, dxsum=parts[:, cb:cb + nf], mask=kb)
                 g["conv" + B + "_weight"] = o.conv3x3_wgrad(ha, dyb, lay)
                 dha = o.conv3x3_dgrad(dyb, p["conv" + B + "_weight"], lay, upk=ub)
                 dya, _, g["bn" + A + "_gamma"], g["bn" + A + "_beta"] = o.bn_bwd(dha, ya, ha, p["bn" + A + "_gamma"], ma, ia,
-                                                                                True, False, lay, dxsum=parts[:, ca:ca + nf])
+                                                                                True, False, lay, dxsum=parts[:, ca:ca + nf], mask=ka)
                 g["conv" + A + "_weight"] = o.conv3x3_wgrad(x, dya, lay)
                 dx = o.conv3x3_dgrad(dya, p["conv" + A + "_weight"], lay, add=dskip, upk=ua)   # trunk + skip gradients meet
             db = o.colsum(parts)

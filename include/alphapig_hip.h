@@ -170,20 +170,23 @@ int apz_wino_conv_add(apz_engine *e, const void *x_dev, const void *upk_dev, con
 /* The training forward of a trunk layer (policy_value_net_mxnet.py:41-56: Convolution, then BatchNorm): y = conv(x, upk)
  * + bias in the padded-row layout, and stats_dev [128][n][2] doubles = per (channel, board) the sum and the sum of
  * squares of the board's 225 outputs, taken in the kernel's epilogue.  apz_bn_fwd_stats = apz_bn_fwd that takes its
- * batch statistics from such a buffer (stats_dev NULL: computes them itself) instead of a pass over x. */
+ * batch statistics from such a buffer (stats_dev NULL: computes them itself) instead of a pass over x.  mask_dev (NULL:
+ * not wanted; padded-row layout): n * C * 60 bytes, bit e of byte i = [element 4 i + e of y > 0] -- apz_bn_bwd reads the
+ * ReLU decisions from it instead of from the 16-times-larger y. */
 int apz_wino_conv_stats(apz_engine *e, const void *x_dev, const void *upk_dev, const void *bias_dev, void *y_dev,
                         void *stats_dev, int n, void *stream);
 int apz_bn_fwd_stats(apz_engine *e, const void *x_dev, const void *resid_dev, const void *gamma_dev,
                      const void *beta_dev, void *run_mean_dev, void *run_var_dev, void *y_dev, void *mean_dev,
-                     void *invstd_dev, const void *stats_dev, int n, int C, int layout, int relu, float momentum,
-                     float eps, void *stream);
+                     void *invstd_dev, const void *stats_dev, void *mask_dev, int n, int C, int layout, int relu,
+                     float momentum, float eps, void *stream);
 /* Training-mode BatchNorm (+ residual) (+ ReLU), the reference's BatchNorm(eps = 1e-3) between the trunk's
  * convolutions (policy_value_net_mxnet.py:41-102), over n x C planes in `layout`:
  *   apz_bn_fwd  y = act((x - mean_c) * invstd_c * gamma_c + beta_c (+ resid)); batch statistics (biased
  *               variance) written to mean_dev / invstd_dev [C] for the backward pass; run_mean / run_var
  *               (may be NULL) updated as run = (1 - momentum) * run + momentum * batch (unbiased variance);
  *               gamma_dev NULL = 1 (the reference's fix_gamma layers)
- *   apz_bn_bwd  dz = dy (* [out > 0] with relu); dbeta = sum dz; dgamma = sum dz * xhat;
+ *   apz_bn_bwd  dz = dy (* [out > 0] with relu: from out_dev, or from mask_dev when given -- then out_dev may be NULL);
+ *               dbeta = sum dz; dgamma = sum dz * xhat;
  *               dx = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M); dres = dz (NULL: not wanted);
  *               dxsum_dev (NULL: not wanted): [apz_bn_bwd_splits(n, C, layout)][dxsum_ld] floats, dxsum_ld >= C;
  *               row s, column c gets the sum of channel c's dx over the boards of batch split s.  The column
@@ -207,7 +210,7 @@ int apz_wgrad_wino(apz_engine *e, const void *x_dev, const void *dy_dev, void *d
  * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) computed by the caller. */
 int apz_adam_step(apz_engine *e, const void *table_host, int ntensors, float lr_t, float b1, float b2,
                   float eps, float rescale, void *stream);
-int apz_bn_bwd(apz_engine *e, const void *dy_dev, const void *x_dev, const void *out_dev,
+int apz_bn_bwd(apz_engine *e, const void *dy_dev, const void *x_dev, const void *out_dev, const void *mask_dev,
                const void *gamma_dev, const void *mean_dev, const void *invstd_dev, void *dx_dev,
                void *dres_dev, void *dgamma_dev, void *dbeta_dev, void *dxsum_dev, int dxsum_ld, int n, int C,
                int layout, int relu, void *stream);

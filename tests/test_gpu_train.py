@@ -226,6 +226,19 @@ def test_bn_batch_splits(n, layout, c):
     assert close(mean, x.double().mean(dim=(0, 2, 3)), 1e-6)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+    if layout == 1:      # the ReLU decisions as a byte per four elements: the same backward pass, bit for bit, without reading y
+        y2, mean2, invstd2, mask = hipconv.bn_fwd(xc, None, bc, None, None, None, True, layout, 0.1, 1e-3, want_mask=True)
+        parts_a = torch.zeros((hipconv.bn_bwd_splits(xc, layout), c), device="cuda")
+        parts_b = torch.zeros_like(parts_a)
+        ra = hipconv.bn_bwd(dyc, xc, y2, None, mean2, invstd2, True, True, layout, dxsum=parts_a)
+        rb = hipconv.bn_bwd(dyc, xc, None, None, mean2, invstd2, True, True, layout, dxsum=parts_b, mask=mask)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y) and mask.dtype == torch.uint8 and tuple(mask.shape) == (n, c, 60)
+        bits = torch.stack([(mask >> e) & 1 for e in range(4)], dim=-1).reshape(n, c, 15, 16).bool()
+        assert torch.equal(bits, y2 > 0)
+        for a, b in zip(ra, rb):
+            assert torch.equal(a, b)
+        assert torch.equal(parts_a, parts_b)
 
 
 @pytest.mark.parametrize("n,c,co,hw,layout", [(9, 128, 4, 15, 1), (9, 128, 2, 15, 1), (5, 128, 4, 15, 0), (6, 256, 4, 8, 0),
