@@ -117,7 +117,7 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_host_free", "apz_encode_planes", "apz_augment8", "apz_sample_moves_host", "apz_sample_moves_keyed_host", "apz_conv3x3_packed_size", "apz_conv3x3_pack",
                "apz_conv3x3_fwd", "apz_conv3x3_wgrad", "apz_wino_packed_size", "apz_wino_pack", "apz_wino_pack_many", "apz_wino_conv",
                "apz_wino_conv_add", "apz_wino_conv_stats", "apz_bn_fwd", "apz_bn_fwd_stats", "apz_bn_bwd", "apz_bn_bwd_splits", "apz_colsum", "apz_adam_step", "apz_wgrad_wino",
-               "apz_conv1x1_fwd", "apz_conv1x1_bwd", "apz_fc_fwd", "apz_fc_bwd", "apz_dropout", "apz_pv_loss",
+               "apz_conv1x1_fwd", "apz_conv1x1_bwd", "apz_conv1x1_bwd2", "apz_fc_fwd", "apz_fc_bwd", "apz_dropout", "apz_pv_loss",
                "apz_layout_convert", "apz_bias_grad", "apz_add", "apz_load_weights_dev",
                "apz_sync", "apz_stream",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
@@ -250,6 +250,7 @@ def hip():
         "apz_wgrad_wino": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
         "apz_adam_step": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "apz_wino_conv_add": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "apz_conv1x1_bwd2": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "apz_conv1x1_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "apz_conv1x1_bwd": (C.c_int, [vp] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "apz_fc_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

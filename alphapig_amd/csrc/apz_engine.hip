@@ -1692,23 +1692,32 @@ int apz_conv1x1_fwd(apz_engine* e, const void* x_dev, const void* w_dev, const v
 
 int apz_conv1x1_bwd(apz_engine* e, const void* x_dev, const void* w_dev, const void* dy_dev, void* dx_dev, void* dw_dev,
                     void* db_dev, int n, int C, int CO, int layout, int accumulate_dx, void* stream) {
-    if (!e || !x_dev || !w_dev || !dy_dev || !dw_dev || n < 1 || C < 1 || C > 1024 || CO < 1 || CO > 8)
+    if (int rc = apz_conv1x1_bwd2(e, x_dev, w_dev, dy_dev, CO, nullptr, nullptr, 0, dx_dev, dw_dev, n, C, layout, accumulate_dx, stream))
+        return rc;
+    if (db_dev) return apz_bias_grad(e, dy_dev, db_dev, n, CO, APZ_LAYOUT_DENSE, stream);
+    return APZ_OK;
+}
+
+int apz_conv1x1_bwd2(apz_engine* e, const void* x_dev, const void* w1_dev, const void* dy1_dev, int CO1, const void* w2_dev,
+                     const void* dy2_dev, int CO2, void* dx_dev, void* dw_dev, int n, int C, int layout, int accumulate_dx,
+                     void* stream) {
+    if (!e || !x_dev || !w1_dev || !dy1_dev || !dw_dev || n < 1 || C < 1 || C > 1024 || CO1 < 1 || CO2 < 0 || CO1 + CO2 > 8 ||
+        (CO2 > 0 && (!w2_dev || !dy2_dev)))
         return fail(APZ_E_ARG, "bad argument");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    const int P = e->cfg.height * e->cfg.width;
+    const int P = e->cfg.height * e->cfg.width, CO = CO1 + CO2;
     if (int rc = head_scratch(e, (size_t)n * CO * C)) return rc;
     const size_t lds = ((size_t)CO * 32 + (size_t)CO * P) * sizeof(float);
-    hipLaunchKernelGGL(apz::conv1x1_bwd_kernel, dim3(n, (C + 31) / 32), dim3(256), lds, e->stream, (const float*)x_dev, (const float*)w_dev,
-                       (const float*)dy_dev, (float*)dx_dev, e->head_scratch, C, CO, e->cfg.height, e->cfg.width, ps, rs,
-                       accumulate_dx);
+    hipLaunchKernelGGL(apz::conv1x1_bwd_kernel, dim3(n, (C + 31) / 32), dim3(256), lds, e->stream, (const float*)x_dev,
+                       (const float*)w1_dev, (const float*)dy1_dev, (const float*)w2_dev, (const float*)dy2_dev, (float*)dx_dev,
+                       e->head_scratch, C, CO1, CO2, e->cfg.height, e->cfg.width, ps, rs, accumulate_dx);
     hipLaunchKernelGGL(apz::colsum_kernel, dim3((CO * C + 63) / 64), dim3(256), 0, e->stream, (const float*)e->head_scratch,
                        (float*)dw_dev, n, CO * C, 1.0f);
     HIP_TRY(hipGetLastError());
-    if (db_dev) return apz_bias_grad(e, dy_dev, db_dev, n, CO, APZ_LAYOUT_DENSE, stream);
     return APZ_OK;
 }
 

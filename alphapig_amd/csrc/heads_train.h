@@ -57,17 +57,26 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restric
 // grid (n, ceil(C / 32)): a workgroup owns 32 channels of a board (one workgroup per board took 92 us for 128 boards:
 // 128 workgroups of dependent loads on 256 CUs).  dw partials: wave w owns the channels 8 w .. 8 w + 7 of the group,
 // lanes walk the pixels (coalesced), the 64 lane sums meet by shuffles.
+// Two heads at once (w2 / dy2 / CO2, CO + CO2 <= 8; CO2 = 0: one): dx = W^T dy + W2^T dy2 in one pass over x and dx (the two
+// heads of the reference share their input: separately the second call re-read x and read-modify-wrote dx, 315 MB instead of
+// 126 MB per 512 boards); part rows: [n][CO + CO2][C], the second head's below the first's.
 __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ dy, float* __restrict__ dx,
-                                                          float* __restrict__ part, int C, int CO, int H, int W, int ps,
+                                                          const float* __restrict__ dy, const float* __restrict__ w2,
+                                                          const float* __restrict__ dy2, float* __restrict__ dx,
+                                                          float* __restrict__ part, int C, int CO1, int CO2, int H, int W, int ps,
                                                           int rs, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [CO][32] weights of the group, [CO][P] dy
+    const int CO = CO1 + CO2;
     const int P = H * W, n = blockIdx.x, c0 = blockIdx.y * 32, nc = min(32, C - c0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* wl = lds;
     float* dl = lds + CO * 32;
-    for (int i = threadIdx.x; i < CO * 32; i += 256) wl[i] = (i & 31) < nc ? w[(i >> 5) * C + c0 + (i & 31)] : 0.f;
-    for (int i = threadIdx.x; i < CO * P; i += 256) dl[i] = dy[(size_t)n * CO * P + i];
+    for (int i = threadIdx.x; i < CO * 32; i += 256) {
+        const int o = i >> 5, c = i & 31;
+        wl[i] = c < nc ? (o < CO1 ? w[o * C + c0 + c] : w2[(o - CO1) * C + c0 + c]) : 0.f;
+    }
+    for (int i = threadIdx.x; i < CO1 * P; i += 256) dl[i] = dy[(size_t)n * CO1 * P + i];
+    for (int i = threadIdx.x; i < CO2 * P; i += 256) dl[CO1 * P + i] = dy2[(size_t)n * CO2 * P + i];
     __syncthreads();
     const float* xb = x + ((size_t)n * C + c0) * ps;
     if (dx) {

@@ -272,6 +272,18 @@ def conv1x1_bwd(x, weight, dy, layout=DENSE, dx=None):
     return dx, dw, db
 
 
+def conv1x1_bwd_pair(x, w1, dy1, w2, dy2, layout=DENSE):
+    """Two 1x1 convolutions of the same input (the two heads): -> (dx, dw1, db1, dw2, db2), dx = both heads' input
+    gradients added, in one pass over x."""
+    L, hnd, stream = _ctx(x, layout)
+    n, c, co1, co2 = int(x.shape[0]), int(x.shape[1]), int(w1.shape[0]), int(w2.shape[0])
+    dx = _empty(tuple(x.shape), x)
+    dw = _empty((co1 + co2, c), x)
+    _ck(L, L.apz_conv1x1_bwd2(hnd, x.data_ptr(), w1.data_ptr(), dy1.data_ptr(), co1, w2.data_ptr(), dy2.data_ptr(), co2,
+                               dx.data_ptr(), dw.data_ptr(), n, c, layout, 0, stream))
+    return dx, dw[:co1].view(w1.shape), bias_grad(dy1, DENSE), dw[co1:].view(w2.shape), bias_grad(dy2, DENSE)
+
+
 def _any_engine(device_index):
     """Operators that do not depend on the board (FullyConnected, Dropout, Adam) run on whichever engine this device
     already has (the net's own board size), else on a 15x15 one."""

@@ -187,8 +187,15 @@ class HipTrainer(object):
             keep = 1.0 - self.dropout
             dpol = o.dropout(dpol, keep, self.seed, 2 * (self.dropout_step0 + tape["step"]))
             dval = o.dropout(dval, keep, self.seed, 2 * (self.dropout_step0 + tape["step"]) + 1)
-        dx = self._conv_act_bwd(dpol.view(n, 4, self.side, self.side), tape["pol"], True)
-        dx = self._conv_act_bwd(dval.view(n, 2, self.side, self.side), tape["val"], True, dx_acc=dx)
+        # the two heads share their input: both BatchNorm backward passes, then ONE pass over the trunk output for dx
+        dys = []
+        for da, rec in ((dpol.view(n, 4, self.side, self.side), tape["pol"]), (dval.view(n, 2, self.side, self.side), tape["val"])):
+            name, _, y, a, mean, invstd, _ = rec
+            dy, _, _, g[name + "_beta"] = o.bn_bwd(da, y, a, None, mean, invstd, True, False, o.DENSE)
+            dys.append(dy)
+        xh = tape["pol"][1]
+        dx, g["conv3_1_1_weight"], g["conv3_1_1_bias"], g["conv3_2_1_weight"], g["conv3_2_1_bias"] = o.conv1x1_bwd_pair(
+            xh, p["conv3_1_1_weight"], dys[0], p["conv3_2_1_weight"], dys[1], tape["pol"][6])
         if self.kind == "resnet":
             upk = tape.get("upk")
             # the trunk convolutions' bias gradients = column sums of the dx their BatchNorms hand back: every bn_bwd

@@ -244,6 +244,11 @@ int apz_conv1x1_fwd(apz_engine *e, const void *x_dev, const void *w_dev, const v
                     int C, int CO, int layout, void *stream);
 int apz_conv1x1_bwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *dy_dev, void *dx_dev,
                     void *dw_dev, void *db_dev, int n, int C, int CO, int layout, int accumulate_dx, void *stream);
+/* ... of two 1x1 convolutions that share their input (the reference's two heads, policy_value_net_mxnet.py:85-96):
+ * dx = W1^T dy1 + W2^T dy2 in one pass over x and dx; dw_dev [CO1 + CO2][C]: the first head's rows, then the second's. */
+int apz_conv1x1_bwd2(apz_engine *e, const void *x_dev, const void *w1_dev, const void *dy1_dev, int CO1,
+                     const void *w2_dev, const void *dy2_dev, int CO2, void *dx_dev, void *dw_dev, int n, int C,
+                     int layout, int accumulate_dx, void *stream);
 int apz_bias_grad(apz_engine *e, const void *dy_dev, void *db_dev, int n, int C, int layout, void *stream);
 int apz_add(apz_engine *e, void *y_dev, const void *x_dev, int64_t count, void *stream);
 int apz_fc_fwd(apz_engine *e, const void *x_dev, const void *w_dev, const void *bias_dev, void *y_dev, int n, int K,

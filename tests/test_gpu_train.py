@@ -241,6 +241,22 @@ def test_bn_batch_splits(n, layout, c):
         assert torch.equal(parts_a, parts_b)
 
 
+def test_head_conv1x1_pair_backward():
+    """The two heads' 1x1 backward in one pass over their shared input == the two separate calls (the second accumulating)."""
+    from alphapig_amd import hipconv
+    g = torch.Generator().manual_seed(5)
+    n = 37
+    x = pad16(torch.randn(n, 128, 15, 15, generator=g)).cuda()
+    w1, w2 = (torch.randn(4, 128, 1, 1, generator=g) / 11).cuda(), (torch.randn(2, 128, 1, 1, generator=g) / 11).cuda()
+    dy1, dy2 = torch.randn(n, 4, 15, 15, generator=g).cuda(), torch.randn(n, 2, 15, 15, generator=g).cuda()
+    dx, dwa, dba = hipconv.conv1x1_bwd(x, w1, dy1, hipconv.ROWS16)
+    dx, dwb, dbb = hipconv.conv1x1_bwd(x, w2, dy2, hipconv.ROWS16, dx=dx)
+    px, pwa, pba, pwb, pbb = hipconv.conv1x1_bwd_pair(x, w1, dy1, w2, dy2, hipconv.ROWS16)
+    torch.cuda.synchronize()
+    assert torch.equal(pwa, dwa) and torch.equal(pwb, dwb) and torch.equal(pba, dba) and torch.equal(pbb, dbb)
+    assert float((px - dx).abs().max()) < 1e-5 * float(dx.abs().max()) and float(px[..., 15].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n,c,co,hw,layout", [(9, 128, 4, 15, 1), (9, 128, 2, 15, 1), (5, 128, 4, 15, 0), (6, 256, 4, 8, 0),
                                               (6, 256, 2, 8, 0), (3, 64, 4, 15, 0), (130, 128, 4, 15, 1)])
 def test_head_conv1x1_forward_backward(n, c, co, hw, layout):
