@@ -49,6 +49,18 @@ def main():
             out["B%d_%s" % (B, backend)] = {"ms_per_step": ms, "conv_tflops_equiv": flops / ms / 1e9}
             print("batch %4d  %-6s  %.2f ms/step   (3x3-conv work %.1f TFLOP/s equivalent)" %
                   (B, backend, ms, flops / ms / 1e9), flush=True)
+            if backend == "hip":     # what epochs 2 .. n of a policy_update pay: the mini-batch is on the device already
+                batch = tr.upload(states, pis, zs)
+                tr.train_step(batch, None, None, 1e-3)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(args.steps):
+                    tr.train_step(batch, None, None, 1e-3)
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t) / args.steps
+                out["B%d_hip_resident_batch" % B] = {"ms_per_step": ms}
+                print("batch %4d  hip     %.2f ms/step on an uploaded mini-batch (HipTrainer.upload: policy_update's epochs share one)" %
+                      (B, ms), flush=True)
     print(json.dumps(out))
 
 
