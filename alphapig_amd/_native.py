@@ -119,7 +119,7 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_wino_conv_add", "apz_wino_conv_stats", "apz_bn_fwd", "apz_bn_fwd_stats", "apz_bn_bwd", "apz_bn_bwd_splits", "apz_colsum", "apz_adam_step", "apz_wgrad_wino",
                "apz_conv1x1_fwd", "apz_conv1x1_bwd", "apz_conv1x1_bwd2", "apz_fc_fwd", "apz_fc_bwd", "apz_dropout", "apz_pv_loss",
                "apz_layout_convert", "apz_bias_grad", "apz_add", "apz_load_weights_dev",
-               "apz_sync", "apz_stream",
+               "apz_sync", "apz_stream", "apz_set_forward_graphs",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
                "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms", "apz_prewarm", "apz_test_select_trunk", "apz_set_trunk_arith"]
 
@@ -244,6 +244,7 @@ def hip():
         "apz_bn_fwd": (C.c_int, [vp] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
         "apz_wino_conv_stats": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
         "apz_bn_fwd_stats": (C.c_int, [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+        "apz_set_forward_graphs": (C.c_int, [vp, C.c_int]),
         "apz_bn_bwd": (C.c_int, [vp] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "apz_bn_bwd_splits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "apz_colsum": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),

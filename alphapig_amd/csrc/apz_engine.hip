@@ -107,6 +107,16 @@ struct apz_engine {
     // public entry points call each other (apz_forward_codes_host -> _async -> apz_encode_planes).  The pipeline
     // workers of SelfPlayEngine submit from their own threads while the main thread may call policy_value_fn,
     // set_params or the arena -- every such call now queues behind the submissions instead of racing them.
+    // apz_submit_codes: the forward of a small batch is tens of launches (one board on the 10-block net: 45), each a few
+    // microseconds of host time -- the third submission of a (slot, batch size) pair captures the launch sequence into a
+    // HIP graph (the slot's code / result buffers and the engine's activation buffers are fixed addresses) and later ones
+    // replay it with one call.  Dropped whenever the weights or the kernel selection change.  OFF by default
+    // (apz_set_forward_graphs): measured on ROCm 7.2 / MI355X (tools/graph_ab.py, profiles/r04_graph_ab.log) the replay is
+    // SLOWER than the plain launches -- BASELINE config 2 (seven launches per 32-board forward) 337 k -> 310 k leaf
+    // evaluations/s, one-board policy_value_fn (45 launches) 0.332 -> 0.338 ms.
+    std::map<long, hipGraphExec_t> fwd_graphs;
+    std::map<long, int> fwd_seen;
+    bool use_graphs = false;
     std::recursive_mutex submit_lock;
     bool ring = false;      // 15x15 / 128-filter resnet: trunk activations in rows16 layout (trunk15_ring.h)
     bool small8 = false;    // 8x8 boards: conv8_kernel / head8_kernel (conv8_small.h)
@@ -568,6 +578,12 @@ int run_trunk(apz_engine* e, const float* planes, int n, int upto, float** resul
     return APZ_OK;
 }
 
+void drop_forward_graphs(apz_engine* e) {
+    for (auto& kv : e->fwd_graphs) hipGraphExecDestroy(kv.second);
+    e->fwd_graphs.clear();
+    e->fwd_seen.clear();
+}
+
 // codes_dev != nullptr (stem_takes_codes(e) only): the position codes instead of `planes`
 bool stem_takes_codes(const apz_engine* e) { return (e->ring && e->cfg.net_kind == APZ_NET_RESNET) || e->small8; }
 
@@ -670,6 +686,7 @@ void apz_destroy(apz_engine* e) {
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
     resolve_pending(e);
+    drop_forward_graphs(e);
     for (auto ev : e->free_events) hipEventDestroy(ev);
     for (auto& l : e->convs) {
         if (l.wpk) hipFree(l.wpk);
@@ -807,6 +824,7 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
                                        std::to_string(p.size));
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
+    drop_forward_graphs(e);              // (weight buffers may move)
     std::vector<double> scale, shift;
     for (auto& L : e->convs) {
         fold_bn(P, L.name, L.bn, L.mean_sfx, L.var_sfx, L.fix_gamma, L.cout, scale, shift);
@@ -1003,6 +1021,9 @@ int apz_forward_codes_host(apz_engine* e, const uint8_t* codes_host, int n, floa
     return APZ_OK;
 }
 
+// batches above this are a handful of long kernels: nothing to gain from a graph
+constexpr int FWD_GRAPH_MAX_BOARDS = 64;
+
 int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) {
     if (!e || !codes_host) return fail(APZ_E_ARG, "null argument");
     if (slot < 0 || slot >= APZ_MAX_SLOTS) return fail(APZ_E_ARG, "slot out of range");
@@ -1026,15 +1047,45 @@ int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) 
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     std::memcpy(sl.h_codes, codes_host, (size_t)n * e->code_stride);
-    int rc;
-    if (stem_takes_codes(e)) {      // the stem decodes the codes itself (read straight from the pinned slot)
-        rc = forward_dev(e, nullptr, n, sl.d_probs, sl.d_values, nullptr, nullptr, sl.d_codes);
+    auto launch_all = [&]() -> int {
+        if (stem_takes_codes(e))    // the stem decodes the codes itself (read straight from the pinned slot)
+            return forward_dev(e, nullptr, n, sl.d_probs, sl.d_values, nullptr, nullptr, sl.d_codes);
+        if (int rc = apz_encode_planes(e, sl.d_codes, n, e->cfg.c_in, e->planes)) return rc;
+        return forward_dev(e, e->planes, n, sl.d_probs, sl.d_values, nullptr, nullptr);
+    };
+    int rc = APZ_OK;
+    const long key = ((long)slot << 32) | (long)n;
+    const bool graphable = e->use_graphs && !e->profiling && n <= FWD_GRAPH_MAX_BOARDS && e->loaded;
+    auto it = graphable ? e->fwd_graphs.find(key) : e->fwd_graphs.end();
+    if (it != e->fwd_graphs.end()) {
+        HIP_TRY(hipGraphLaunch(it->second, e->stream));
+        e->last_n = n;
+    } else if (graphable && ++e->fwd_seen[key] >= 3 && e->w3s_epoch < 0xFFFF0000u) {
+        // (third use: every lazy allocation / attribute / ticket reset of this shape has happened outside the capture)
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        rc = launch_all();
+        const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+        if (rc) {
+            if (graph) hipGraphDestroy(graph);
+            return rc;
+        }
+        if (ce != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            e->use_graphs = false;          // this runtime cannot capture the sequence: plain launches from here on
+            rc = launch_all();
+            if (rc) return rc;
+        } else {
+            hipGraphDestroy(graph);
+            e->fwd_graphs[key] = exec;
+            HIP_TRY(hipGraphLaunch(exec, e->stream));
+        }
     } else {
-        rc = apz_encode_planes(e, sl.d_codes, n, e->cfg.c_in, e->planes);
+        rc = launch_all();
         if (rc) return rc;
-        rc = forward_dev(e, e->planes, n, sl.d_probs, sl.d_values, nullptr, nullptr);
     }
-    if (rc) return rc;
     HIP_TRY(hipEventRecord(sl.done, e->stream));
     sl.n = n;
     sl.busy = true;
@@ -1170,6 +1221,7 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
                          void* stream) {
     if (!e || !names || !dev_ptrs || !sizes) return fail(APZ_E_ARG, "null argument");
     EngineLock guard(e->submit_lock);
+    drop_forward_graphs(e);
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (!e->loaded) return fail(APZ_E_STATE, "apz_load_weights_dev refreshes a loaded engine: call apz_load_weights first");
     std::map<std::string, const float*> P;
@@ -1968,6 +2020,10 @@ int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
 }
 
 int apz_set_trunk_arith(apz_engine* e, int arith) {
+    if (e) {
+        EngineLock guard_(e->submit_lock);
+        drop_forward_graphs(e);
+    }
     if (!e || (arith != APZ_ARITH_F32 && arith != APZ_ARITH_BF16X3)) return fail(APZ_E_ARG, "bad trunk arithmetic");
     EngineLock guard(e->submit_lock);
     if (arith == APZ_ARITH_BF16X3 && !e->ring)
@@ -1979,6 +2035,10 @@ int apz_set_trunk_arith(apz_engine* e, int arith) {
 }
 
 int apz_test_select_trunk(apz_engine* e, int kind) {
+    if (e) {
+        EngineLock guard_(e->submit_lock);
+        drop_forward_graphs(e);
+    }
     if (!e || (kind != APZ_TRUNK_WINOGRAD && kind != APZ_TRUNK_DIRECT && kind != APZ_TRUNK_WINOGRAD_BATCHED &&
                kind != APZ_TRUNK_WINOGRAD_NO_QUARTER))
         return fail(APZ_E_ARG, "bad trunk kernel kind");
@@ -1987,6 +2047,14 @@ int apz_test_select_trunk(apz_engine* e, int kind) {
     e->trunk_kernel = kind == APZ_TRUNK_DIRECT ? APZ_TRUNK_DIRECT : APZ_TRUNK_WINOGRAD;
     e->no_small_trunk = kind == APZ_TRUNK_WINOGRAD_BATCHED || kind == APZ_TRUNK_WINOGRAD_NO_QUARTER;
     e->no_quarter_trunk = kind == APZ_TRUNK_WINOGRAD_NO_QUARTER;
+    return APZ_OK;
+}
+
+int apz_set_forward_graphs(apz_engine* e, int on) {
+    if (!e) return fail(APZ_E_ARG, "null engine");
+    EngineLock guard(e->submit_lock);
+    e->use_graphs = on != 0;
+    if (!on) drop_forward_graphs(e);
     return APZ_OK;
 }
 

@@ -281,6 +281,10 @@ int apz_layer_io(apz_engine *e, int layer, float *host_out, int64_t count);
  * on = k > 1 every k-th forward (the event records cost a few us per kernel, so sampled timing
  * keeps the measured run undisturbed); then read out[0] = total ms, out[1] = timed launches
  * (resolved at apz_sync). */
+/* on != 0: apz_submit_codes replays the launch sequence of a small batch (<= 64 boards) as a HIP graph from the third
+ * submission of a (slot, batch size) pair on (results unchanged: the same kernels with the same arguments).  Default: off
+ * -- measured slower than the plain launches on ROCm 7.2 (profiles/r04_graph_ab.log). */
+int apz_set_forward_graphs(apz_engine *e, int on);
 int apz_set_profiling(apz_engine *e, int on);
 /* TEST HOOK.  The 15x15 / 128-filter residual net has two trunk convolution kernels: the fused F(4x4,3x3) Winograd kernel
  * (default, csrc/trunk15_wino3.h) and the direct convolution (csrc/trunk15_ring.h) that the tests use as the in-tree

@@ -569,3 +569,57 @@ def test_bf16x3_weights_packed_on_the_device_equal_the_host_pack():
         host._ck(host.L.apz_set_trunk_arith(host._h, 0))
     host.close()
     dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,nrow", [("resnet", 15, 5), ("simple", 8, 4)])
+def test_forward_graph_replay_is_the_plain_launch_sequence(kind, w, nrow):
+    """apz_submit_codes captures the launch sequence of a small batch into a HIP graph on the third submission of a
+    (slot, batch size) pair and replays it afterwards: the same kernels with the same arguments, so the same bits as
+    plain launches -- across batch sizes and slots, for new positions in the slot's buffer, and after a weight change
+    (which drops the graphs: policy_value_net_mxnet.py:244-259 through policy_value_fn / the self-play engine's slots)."""
+    from alphapig_amd.game import Board
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    prm = weights.init_params(kind, w, w, 9, 2, 128, seed=21, style="bench")
+    net = PolicyValueNet(w, w, batch_size=64, n_blocks=2, n_filter=128, model_params=prm, net_kind=kind)
+    rs = np.random.RandomState(4)
+    codes = []
+    for i in range(40):
+        b = Board(width=w, height=w, n_in_row=nrow)
+        b.init_board(0)
+        for _ in range(rs.randint(0, 12)):
+            b.do_move(int(rs.choice(b.availables)))
+        codes.append(b.position_codes())
+    codes = np.stack(codes)
+
+    def run(slot, lo, n):
+        k = net.submit_codes_slot(slot, codes[lo:lo + n])
+        p, v = net.wait_slot(slot, k)
+        return np.array(p, copy=True), np.array(v, copy=True)
+
+    shapes = [(0, 0, 1), (1, 3, 7), (0, 8, 32), (2, 0, 33)]
+    net._ck(net.L.apz_set_forward_graphs(net._h, 0))
+    plain = {s: run(*s) for s in shapes}
+    plain_b = run(0, 5, 1)                                  # other positions, batch size 1, slot 0
+    net._ck(net.L.apz_set_forward_graphs(net._h, 1))
+    for rep in range(6):                                    # submissions 1, 2: plain; 3: captured + launched; 4 ..: replayed
+        for s in shapes:
+            p, v = run(*s)
+            np.testing.assert_array_equal(p, plain[s][0])
+            np.testing.assert_array_equal(v, plain[s][1])
+    p, v = run(0, 5, 1)                                     # the replayed graph reads the slot's buffer: new positions
+    np.testing.assert_array_equal(p, plain_b[0])
+    np.testing.assert_array_equal(v, plain_b[1])
+    prm2 = weights.init_params(kind, w, w, 9, 2, 128, seed=22, style="bench")
+    net.set_params(prm2)                                    # graphs dropped; the next submissions use the new weights
+    fresh = PolicyValueNet(w, w, batch_size=64, n_blocks=2, n_filter=128, model_params=prm2, net_kind=kind)
+    fresh._ck(fresh.L.apz_set_forward_graphs(fresh._h, 0))
+    for rep in range(5):
+        p, v = run(1, 3, 7)
+        k = fresh.submit_codes_slot(1, codes[3:10])
+        pf, vf = fresh.wait_slot(1, k)
+        np.testing.assert_array_equal(p, np.asarray(pf))
+        np.testing.assert_array_equal(v, np.asarray(vf))
+    assert float(np.abs(p - plain[(1, 3, 7)][0]).max()) > 0
+    net.close()
+    fresh.close()
