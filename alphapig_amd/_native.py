@@ -73,6 +73,7 @@ def host():
         "apzh_codes_to_planes": (C.c_int, [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
         "apzh_advance": (C.c_int, [vp, i32p, C.c_int, i32p, u8p]),
         "apzh_feed": (C.c_int, [vp, i32p, C.c_int, f32p, f32p]),
+        "apzh_feed_advance": (C.c_int, [vp, i32p, C.c_int, f32p, f32p, i32p, u8p]),
         "apzh_feed_sparse": (C.c_int, [vp, C.c_int, i32p, f64p, C.c_int, C.c_double, C.c_int]),
         "apzh_pending_path": (C.c_int, [vp, C.c_int, i16p, C.c_int]),
         "apzh_playouts_done": (C.c_int, [vp, C.c_int]),
@@ -105,7 +106,7 @@ def host():
 HOST_SYMBOLS = ["apzh_last_error", "apzh_version", "apzh_create", "apzh_destroy", "apzh_game_reset",
                 "apzh_game_set_position", "apzh_game_do_move", "apzh_game_status", "apzh_game_history",
                 "apzh_game_has_a_winner", "apzh_code_stride", "apzh_game_codes", "apzh_codes_to_planes",
-                "apzh_advance", "apzh_feed", "apzh_feed_sparse", "apzh_pending_path", "apzh_playouts_done",
+                "apzh_advance", "apzh_feed", "apzh_feed_advance", "apzh_feed_sparse", "apzh_pending_path", "apzh_playouts_done",
                 "apzh_set_playouts_done", "apzh_set_n_playout", "apzh_node_children", "apzh_set_prior_mode",
                 "apzh_root_visits_dense", "apzh_update_with_move", "apzh_play_move", "apzh_play_moves", "apzh_stats",
                 "apzh_pool_info", "apzh_pure_get_move", "apzh_mt_seed", "apzh_np_sum", "apzh_root_sample",

@@ -704,6 +704,26 @@ int apzh_advance(apzh_pool *p, const int32_t *games, int n, int32_t *status, uin
     return APZH_OK;
 }
 
+static inline void feed_one(apzh_pool *p, Game &g, const float *pr, float value) {
+    const int hw = p->hw;
+    Arena &t = g.tree[g.cur];
+    int cnt = 0;
+    for (int m = 0; m < hw; m++) cnt += (g.cells[m] == 0);
+    int32_t leaf = g.pending_leaf;
+    int32_t base = t.alloc(cnt);
+    t.first_child[leaf] = base;
+    t.n_child[leaf] = (int16_t)cnt;
+    int k = 0;
+    for (int m = 0; m < hw; m++) {
+        if (g.cells[m]) continue;
+        t.parent[base + k] = leaf;
+        t.action[base + k] = (int16_t)m;
+        t.prior[base + k] = (double)pr[m];
+        k++;
+    }
+    finish_pending(p, g, (double)value, true);
+}
+
 int apzh_feed(apzh_pool *p, const int32_t *games, int n, const float *probs, const float *values) {
     CHECK_POOL(p);
     if (!games || !probs || !values || n < 0) return fail(APZH_E_ARG, "bad arguments");
@@ -711,27 +731,29 @@ int apzh_feed(apzh_pool *p, const int32_t *games, int n, const float *probs, con
         if (games[i] < 0 || games[i] >= p->cfg.n_games) return fail(APZH_E_ARG, "game index out of range");
         if (!p->games[games[i]].pending) return fail(APZH_E_STATE, "feed without a pending leaf");
     }
-    const int hw = p->hw;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(p->nthreads) if (n > 8)
+    for (int i = 0; i < n; i++) feed_one(p, p->games[games[i]], probs + (size_t)i * p->hw, values[i]);
+    return APZH_OK;
+}
+
+/* apzh_feed followed by apzh_advance on the same games, one parallel region and one call: the step of a 32-leaf group (BASELINE
+ * config 2) is two tree calls + their Python glue otherwise */
+int apzh_feed_advance(apzh_pool *p, const int32_t *games, int n, const float *probs, const float *values, int32_t *status,
+                      uint8_t *codes) {
+    CHECK_POOL(p);
+    if (!games || !probs || !values || !status || n < 0) return fail(APZH_E_ARG, "bad arguments");
+    std::vector<char> seen((size_t)p->cfg.n_games, 0);
+    for (int i = 0; i < n; i++) {
+        if (games[i] < 0 || games[i] >= p->cfg.n_games) return fail(APZH_E_ARG, "game index out of range");
+        if (!p->games[games[i]].pending) return fail(APZH_E_STATE, "feed without a pending leaf");
+        if (seen[games[i]]++) return fail(APZH_E_ARG, "a game twice in one call");
+    }
+    const int stride = apzh_code_stride(p->cfg.height, p->cfg.width);
 #pragma omp parallel for schedule(dynamic, 4) num_threads(p->nthreads) if (n > 8)
     for (int i = 0; i < n; i++) {
         Game &g = p->games[games[i]];
-        Arena &t = g.tree[g.cur];
-        const float *pr = probs + (size_t)i * hw;
-        int cnt = 0;
-        for (int m = 0; m < hw; m++) cnt += (g.cells[m] == 0);
-        int32_t leaf = g.pending_leaf;
-        int32_t base = t.alloc(cnt);
-        t.first_child[leaf] = base;
-        t.n_child[leaf] = (int16_t)cnt;
-        int k = 0;
-        for (int m = 0; m < hw; m++) {
-            if (g.cells[m]) continue;
-            t.parent[base + k] = leaf;
-            t.action[base + k] = (int16_t)m;
-            t.prior[base + k] = (double)pr[m];
-            k++;
-        }
-        finish_pending(p, g, (double)values[i], true);
+        feed_one(p, g, probs + (size_t)i * p->hw, values[i]);
+        status[i] = advance_one(p, g, codes ? codes + (size_t)i * stride : nullptr);
     }
     return APZH_OK;
 }

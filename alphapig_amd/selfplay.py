@@ -236,14 +236,23 @@ class SelfPlayEngine(object):
                 self._start_game(s)
 
     # ---- scheduling ------------------------------------------------------------------------
-    def _advance_group(self, ids):
+    def _advance_group(self, ids, fed=None):
         """Advance the slots in `ids` until each one waits for an evaluation (or went idle).
+        fed = (ids, probs, values) of the group's finished evaluation, not fed to the trees yet: when those are exactly
+        the group's active slots (the steady state) feed + first advance are ONE native call (apzh_feed_advance).
         -> (eval_ids, eval_codes)"""
         t0 = time.perf_counter()
         ids = np.array([s for s in ids if self.slots[s].active], dtype=np.int32)
+        fused = fed is not None and len(fed[0]) == len(ids) and np.array_equal(np.asarray(fed[0], dtype=np.int32), ids)
+        if fed is not None and not fused:
+            self.pool.feed(fed[0], fed[1], fed[2])
         eval_ids, eval_codes = [], []
         while len(ids):
-            st, codes = self.pool.advance(ids)
+            if fused:
+                st, codes = self.pool.feed_advance(ids, fed[1], fed[2])
+                fused = False
+            else:
+                st, codes = self.pool.advance(ids)
             need = st == NEED_EVAL
             if need.any():
                 eval_ids.append(ids[need])
@@ -314,13 +323,12 @@ class SelfPlayEngine(object):
             busy = False
             t_step = time.perf_counter()
             for gi, grp in enumerate(groups):
+                fed = None
                 if gi in inflight:                       # finish this group's previous evaluation
                     p, v, ids = self._collect(inflight.pop(gi))
-                    t0 = time.perf_counter()
-                    self.pool.feed(ids, p, v)
-                    self.timers["host_s"] += time.perf_counter() - t0
+                    fed = (ids, p, v)
                     leafs += len(ids)
-                ids, codes = self._advance_group(grp)    # overlaps the other groups' evaluations
+                ids, codes = self._advance_group(grp, fed)   # (feeds first) overlaps the other groups' evaluations
                 if len(ids):
                     busy = True
                     inflight[gi] = self._dispatch(gi, ids, codes)

@@ -115,6 +115,20 @@ class TreePool(object):
         self._ck(self.L.apzh_feed(self._h, as_ptr(games, C.c_int32), n, as_ptr(probs, C.c_float),
                                   as_ptr(values, C.c_float)))
 
+    def feed_advance(self, games, probs, values):
+        """feed(games, probs, values), then advance(games): one native call -> (status, codes)"""
+        games = np.ascontiguousarray(games, dtype=np.int32)
+        probs = np.ascontiguousarray(probs, dtype=np.float32)
+        values = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+        n = len(games)
+        if probs.shape != (n, self.hw) or values.shape != (n,):
+            raise ValueError("probs must be [n, H*W] and values [n]")
+        st = np.empty(n, dtype=np.int32)
+        cd = np.empty((n, self.code_stride), dtype=np.uint8)
+        self._ck(self.L.apzh_feed_advance(self._h, as_ptr(games, C.c_int32), n, as_ptr(probs, C.c_float),
+                                          as_ptr(values, C.c_float), as_ptr(st, C.c_int32), as_ptr(cd, C.c_uint8)))
+        return st, cd
+
     def feed_sparse(self, g, actions, priors, value, value_is_f32):
         a = np.ascontiguousarray(actions, dtype=np.int32)
         p = np.ascontiguousarray(priors, dtype=np.float64)

@@ -99,6 +99,9 @@ int apzh_advance(apzh_pool *p, const int32_t *games, int n, int32_t *status, uin
  * probs[i][H*W] (children = empty cells ascending, priors = probs[i][cell], not
  * renormalised: policy_value_net_mxnet.py:274) and value values[i] (float32 semantics). */
 int apzh_feed(apzh_pool *p, const int32_t *games, int n, const float *probs, const float *values);
+/* apzh_feed, then apzh_advance, on the same games in one call (no game twice): status / codes as apzh_advance */
+int apzh_feed_advance(apzh_pool *p, const int32_t *games, int n, const float *probs, const float *values,
+                      int32_t *status, uint8_t *codes);
 /* Same for one game with an explicit (action, prior) list in caller order (drop-in
  * policy_value_fn path).  value_is_f32: 1 float32 value, 0 python float. */
 int apzh_feed_sparse(apzh_pool *p, int g, const int32_t *actions, const double *priors, int n,
