@@ -1666,11 +1666,18 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     }
     bool& attr = e->lds_attr_set[10];
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
         attr = true;
     }
-    hipLaunchKernelGGL(apz::wgrad_wino3_kernel, dim3(T3::BLOCKS * slices), dim3(T3::THREADS), T3::LDS_BYTES, e->stream,
-                       (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
+    // rows through raw buffer loads (hardware zero fill for rows off the board, scalar board offset) from 256 boards on:
+    // 133.6 against 144.4 us at 512 boards, 38.7 against 37.8 us at 128 (same box, alternating rounds: tools/wgrad_kernel_bench.hip)
+    if (n >= 256)
+        hipLaunchKernelGGL(apz::wgrad_wino3_kernel<true>, dim3(T3::BLOCKS * slices), dim3(T3::THREADS), T3::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
+    else
+        hipLaunchKernelGGL(apz::wgrad_wino3_kernel<false>, dim3(T3::BLOCKS * slices), dim3(T3::THREADS), T3::LDS_BYTES, e->stream,
+                           (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, spx);
     hipLaunchKernelGGL(apz::wgrad_wino_finish_kernel, dim3(128 * 128 * 9 / 4 / 256), dim3(256), 0, e->stream,
                        (const float*)e->wgw_scratch, slices, (float*)dw_dev);
     HIP_TRY(hipGetLastError());

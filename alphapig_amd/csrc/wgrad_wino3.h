@@ -22,11 +22,12 @@
 // (V = B^T d B), waves 4..7 its 32 gradient planes (dM = A dY A^T).  The operand arrays are double-buffered, so there is
 // ONE barrier per half board, and a wave that is done with a half's MFMAs goes straight on to the next half's transform
 // while the SIMD's other wave still feeds the matrix pipe.  Input planes are read by four workgroups instead of two (all
-// of a slice's sixteen blocks sit on one XCD: L2 hits).  145 us per 512 boards (0.42 of the fp32 matrix peak), 40 us at 128.
+// of a slice's sixteen blocks sit on one XCD: L2 hits).  134 - 145 us per 512 boards (0.42 - 0.46 of the fp32 matrix peak), 38 - 40 us at 128.
 // What bounds it now: the fp32 matrix instructions run on the vector unit's FMA lanes, so a half board costs its 2 304
 // cycles of MFMAs PLUS ~1 800 cycles of transform instructions (373 per SIMD and half at ~4.8 cycles each), + ~700 of
-// barrier and loop ends; packed two-wide transform arithmetic and buffer loads with hardware zero fill were measured and
-// changed nothing (146.7 / 149.7 us).
+// barrier and loop ends; packed two-wide transform arithmetic was measured and changed nothing (the repacking moves eat
+// the gain); raw buffer loads with hardware zero fill instead of 37 selects: 133.6 against 144.4 us at 512 boards
+// (0.46 of the peak), slightly slower at 128 -- chosen by batch size.
 //
 // LDS: two operand sets of V [36][2 groups][8 tiles][16] + dM [36][2 groups][8 tiles][16]; channel c of tile t sits in slot
 // (c + 4 (t >> 1)) & 15 of its (position, group, tile) row: the transform's stores (lane = plane x tile) and the MFMA's
@@ -87,6 +88,9 @@ static_assert(WgradWino3::LDS_BYTES <= 160 * 1024, "LDS");
 // x, dy: padded-row layout [n][128][15][16].  scratch: [slices][128 co][128 ci][3][3] (partial dg per batch slice; added by
 // wgrad_wino_finish_kernel).  Grid: 8 * BLOCKS * spx workgroups, slices = 8 * spx.  Workgroup L (dispatched round-robin
 // over the XCDs, L mod 8 = its XCD) takes slice (L mod 8) * spx + (L / 8) / BLOCKS and channel block (L / 8) mod BLOCKS.
+// BUF: the patch rows through raw buffer loads (a row off the board gets an offset beyond the buffer and reads as zero: no
+// selects; the board offset is a scalar) -- 7 % faster at 512 boards, 2 % slower at 128: the launcher picks by batch size.
+template <bool BUF = false>
 __global__ __launch_bounds__(512) void wgrad_wino3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ scratch, int n, int spx) {
     using T = WgradWino3;
@@ -116,6 +120,9 @@ __global__ __launch_bounds__(512) void wgrad_wino3_kernel(const float* __restric
     const int ch = (wave & 3) * 8 + pl;                             // channel of the block's 32
     const int tile = tr * 4 + ttx, c16 = ch & 15, grp = ch >> 4;    // tile of the half, channel of the 16-channel group, group
     const int wslot = grp * 128 + tile * 16 + ((c16 + 4 * (tile >> 1)) & 15);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad ? dy : x), 0, (unsigned)n * T::C * T::GPLANE * 4u, 0x00020000);
+    const unsigned plane_off = (unsigned)(((grad ? cob * T::CO_B : cib * T::CI_B) + ch) * T::GPLANE + 4 * ttx) * 4u;
     const float* plane0 = grad ? dy + ((size_t)cob * T::CO_B + ch) * T::GPLANE + 4 * ttx : x + ((size_t)cib * T::CI_B + ch) * T::GPLANE + 4 * ttx;
 
     const int nboards = slice < n ? (n - slice + slices - 1) / slices : 0;
@@ -129,13 +136,18 @@ __global__ __launch_bounds__(512) void wgrad_wino3_kernel(const float* __restric
         const int uu = u < total ? u : total - 1;     // (past the end: a harmless repeat)
         const int b = slice + (uu >> 1) * slices, trow = 2 * (uu & 1) + tr;
         const float* pb = plane0 + (size_t)b * T::C * T::GPLANE;
+        const unsigned soff = (unsigned)b * (unsigned)(T::C * T::GPLANE * 4);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             if (grad && i >= 4) break;
             const int R = grad ? 4 * trow + i : 4 * trow - 1 + i;
             const bool in = R >= 0 && R <= 14;
-            nx[i] = *reinterpret_cast<const f32x4*>(pb + (in ? R : 0) * 16);
-            if (!in) nx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BUF) {
+                nx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? plane_off + (unsigned)R * 64u : 0x80000000u, soff, 0));
+            } else {
+                nx[i] = *reinterpret_cast<const f32x4*>(pb + (in ? R : 0) * 16);
+                if (!in) nx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     if (total > 0) prefetch(0);

@@ -24,7 +24,8 @@
 int main() {
     using T3 = apz::WgradWino3;
     const int ROT = 4;
-    CK(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
     for (int n : {64, 128, 131, 512}) {
         const size_t plane = (size_t)n * 128 * 240;
         std::vector<float> h(plane);
@@ -42,9 +43,14 @@ int main() {
         hipEvent_t a_ev, b_ev;
         CK(hipEventCreate(&a_ev));
         CK(hipEventCreate(&b_ev));
+        bool buf = false;
         auto run = [&](int it, bool finish) {
-            hipLaunchKernelGGL(apz::wgrad_wino3_kernel, dim3(T3::BLOCKS * slices), dim3(T3::THREADS), T3::LDS_BYTES, 0, x[it % ROT],
-                               dy[it % ROT], scratch, n, spx);
+            if (buf)
+                hipLaunchKernelGGL(apz::wgrad_wino3_kernel<true>, dim3(T3::BLOCKS * slices), dim3(T3::THREADS), T3::LDS_BYTES, 0, x[it % ROT],
+                                   dy[it % ROT], scratch, n, spx);
+            else
+                hipLaunchKernelGGL(apz::wgrad_wino3_kernel<false>, dim3(T3::BLOCKS * slices), dim3(T3::THREADS), T3::LDS_BYTES, 0, x[it % ROT],
+                                   dy[it % ROT], scratch, n, spx);
             if (finish)
                 hipLaunchKernelGGL(apz::wgrad_wino_finish_kernel, dim3(128 * 128 * 9 / 4 / 256), dim3(256), 0, 0, scratch, slices, dw);
         };
@@ -59,18 +65,19 @@ int main() {
                 printf("  wave %d: %8llu %8llu %8llu %8llu %8llu %8llu\n", w, st[w][0], st[w][1], st[w][2], st[w][3], st[w][4], st[w][5]);
         }
 #endif
-        for (int f = 0; f < 2; f++) {
-            for (int it = 0; it < 5; it++) run(it, f);
+        for (int f = 0; f < 12; f++) {
+            buf = (f >> 1) & 1;                       // rounds alternate plain loads / buffer loads (kernel, then kernel + finish, each)
+            for (int it = 0; it < 5; it++) run(it, f & 1);
             CK(hipDeviceSynchronize());
             const int iters = 40;
             CK(hipEventRecord(a_ev));
-            for (int it = 0; it < iters; it++) run(it, f);
+            for (int it = 0; it < iters; it++) run(it, f & 1);
             CK(hipEventRecord(b_ev));
             CK(hipEventSynchronize(b_ev));
             float ms;
             CK(hipEventElapsedTime(&ms, a_ev, b_ev));
-            printf("n=%d (%d slices) transform=%d mfma=%d %s: %.1f us  (%.3f of the fp32 matrix peak)\n", n, slices, !APZ_WGW3_NO_TRANSFORM,
-                   !APZ_WGW3_NO_MFMA, f ? "kernel + finish" : "kernel", ms * 1e3 / iters, n * 9216.0 * 2048.0 / (ms * 1e-3 / iters) / 157.3e12);
+            printf("n=%d (%d slices) transform=%d mfma=%d %s %s: %.1f us  (%.3f of the fp32 matrix peak)\n", n, slices, !APZ_WGW3_NO_TRANSFORM,
+                   !APZ_WGW3_NO_MFMA, buf ? "buffer loads" : "plain loads", (f & 1) ? "kernel + finish" : "kernel", ms * 1e3 / iters, n * 9216.0 * 2048.0 / (ms * 1e-3 / iters) / 157.3e12);
         }
         for (int r = 0; r < ROT; r++) {
             CK(hipFree(x[r]));
