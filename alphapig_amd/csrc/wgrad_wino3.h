@@ -25,8 +25,8 @@
 // of a slice's sixteen blocks sit on one XCD: L2 hits).  134 - 145 us per 512 boards (0.42 - 0.46 of the fp32 matrix peak), 38 - 40 us at 128.
 // What bounds it now: the fp32 matrix instructions run on the vector unit's FMA lanes, so a half board costs its 2 304
 // cycles of MFMAs PLUS ~1 800 cycles of transform instructions (373 per SIMD and half at ~4.8 cycles each), + ~700 of
-// barrier and loop ends; packed two-wide transform arithmetic was measured and changed nothing (the repacking moves eat
-// the gain); raw buffer loads with hardware zero fill instead of 37 selects: 133.6 against 144.4 us at 512 boards
+// barrier and loop ends; packed two-wide transform arithmetic was measured twice (rows-then-columns with repacking moves; columns-first
+// with none: 72 + 36 instead of 144 instructions) and changed nothing in same-box A/B runs (133.3 against 132.7 us); raw buffer loads with hardware zero fill instead of 37 selects: 133.6 against 144.4 us at 512 boards
 // (0.46 of the peak), slightly slower at 128 -- chosen by batch size.
 //
 // LDS: two operand sets of V [36][2 groups][8 tiles][16] + dM [36][2 groups][8 tiles][16]; channel c of tile t sits in slot
