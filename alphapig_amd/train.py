@@ -201,8 +201,9 @@ class HipTrainer(object):
             upk = tape.get("upk")
             # the trunk convolutions' bias gradients = column sums of the dx their BatchNorms hand back: every bn_bwd
             # leaves its per-split sums in its own columns of ONE matrix, added after the loop in one launch
-            nb, nf = self.n_blocks, int(tape["blocks"][0][1].shape[1])
-            parts = o._empty((o.bn_bwd_splits(tape["blocks"][0][1], lay), 2 * nb * nf), dx)
+            nb = self.n_blocks
+            nf = int(tape["blocks"][0][1].shape[1]) if nb else 0
+            parts = o._empty((o.bn_bwd_splits(tape["blocks"][0][1], lay), 2 * nb * nf), dx) if nb else None
             for i in range(nb, 0, -1):
                 A, B = "A%d" % i, "B%d" % i
                 x, ya, ha, ma, ia, yb, out, mb, ib, ka, kb = tape["blocks"][i - 1]
@@ -216,7 +217,7 @@ class HipTrainer(object):
                                                                                 True, False, lay, dxsum=parts[:, ca:ca + nf], mask=ka)
                 g["conv" + A + "_weight"] = o.conv3x3_wgrad(x, dya, lay)
                 dx = o.conv3x3_dgrad(dya, p["conv" + A + "_weight"], lay, add=dskip, upk=ua)   # trunk + skip gradients meet
-            db = o.colsum(parts)
+            db = o.colsum(parts) if nb else None
             for i in range(1, nb + 1):
                 g["convA%d_bias" % i] = db[(2 * i - 2) * nf:(2 * i - 1) * nf]
                 g["convB%d_bias" % i] = db[(2 * i - 1) * nf:2 * i * nf]
