@@ -159,8 +159,9 @@ def conv3x3_wgrad(x, dy, layout=DENSE):
     L, hnd, stream = _ctx(x, layout)
     n, ci, co = int(x.shape[0]), int(x.shape[1]), int(dy.shape[1])
     dw = _empty((co, ci, 3, 3), x)
-    # through the Winograd domain (3.6x fewer MFMAs) once the batch covers its per-slice partial sums
-    if layout == ROWS16 and (ci, co) == (128, 128) and n >= 64:
+    # through the Winograd domain (3.6x fewer MFMAs; wgrad_wino3_kernel beats the direct kernel from 8 boards on: 14 against
+    # 35 us at 8 boards, 22 against 48 at 32 -- round 3's kernel needed 64 boards to cover its per-slice partial sums)
+    if layout == ROWS16 and (ci, co) == (128, 128):
         _ck(L, L.apz_wgrad_wino(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, stream))
     else:
         _ck(L, L.apz_conv3x3_wgrad(hnd, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, ci, co, layout, stream))
