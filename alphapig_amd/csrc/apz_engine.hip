@@ -137,7 +137,7 @@ struct apz_engine {
     double* fold_ws = nullptr;                     // apz_load_weights_dev: scale / shift of one layer (2 x 256 doubles)
     float* head_scratch = nullptr;                 // apz_conv1x1_bwd / apz_pv_loss: per-board partial sums
     size_t head_scratch_floats = 0;
-    int wgw_slices = 0;
+    size_t wgw_floats = 0;                         // capacity of wgw_scratch
     void* adam_tab = nullptr;                      // apz_adam_step: device copy of the tensor table
     size_t adam_cap = 0;
     float* wino_scratch[2] = {nullptr, nullptr};   // apz_wino_conv: rows16 input / output copies
@@ -1474,6 +1474,20 @@ int apz_wino_conv(apz_engine* e, const void* x_dev, const void* upk_dev, const v
     return apz_wino_conv_add(e, x_dev, upk_dev, bias_dev, nullptr, y_dev, n, relu, layout, stream);
 }
 
+namespace {
+int wgrad_scratch(apz_engine* e, size_t floats) {   // per-slice partial weight gradients (both weight-gradient kernels)
+    if (floats > e->wgw_floats) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (e->wgw_scratch) HIP_TRY(hipFree(e->wgw_scratch));
+        e->wgw_scratch = nullptr;
+        e->wgw_floats = 0;
+        HIP_TRY(hipMalloc((void**)&e->wgw_scratch, floats * sizeof(float)));
+        e->wgw_floats = floats;
+    }
+    return APZ_OK;
+}
+}  // namespace
+
 int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void* dw_dev, int n, int cin, int cout,
                       int layout, void* stream) {
     if (!e || !x_dev || !dy_dev || !dw_dev || n < 1 || cin < 1 || cout < 32 || cout % 32 || layout < 0 || layout > 1)
@@ -1483,7 +1497,6 @@ int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
     StreamScope sc(e, stream);
-    HIP_TRY(hipMemsetAsync(dw_dev, 0, (size_t)cout * cin * 9 * sizeof(float), e->stream));
     const int H = e->cfg.height, W = e->cfg.width;
     const int gx = cout / 32, gy = (cin + 63) / 64;
     int slices = std::max(1, std::min(n, (e->num_cu * 2) / std::max(1, gx * gy)));
@@ -1495,6 +1508,7 @@ int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void
             e->wgrad_attr_set[0] = true;
         }
         slices = std::max(1, std::min(n, e->num_cu / std::max(1, gx * gy)));   // 85 KB LDS: one workgroup per CU
+        if (int rc = wgrad_scratch(e, (size_t)slices * cout * cin * 9)) return rc;
         if (layout == APZ_LAYOUT_ROWS16) {
             using G16 = apz::WgradGeo<15, 15, true>;
             bool& set16 = e->lds_attr_set[8];       // per engine (= per device), like every other attribute flag
@@ -1504,22 +1518,26 @@ int apz_conv3x3_wgrad(apz_engine* e, const void* x_dev, const void* dy_dev, void
                 set16 = true;
             }
             hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<15, 15, true>), dim3(gx, gy, slices), dim3(256), G16::LDS_BYTES,
-                               e->stream, (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
+                               e->stream, (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, cin, cout);
         } else
             hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<15, 15>), dim3(gx, gy, slices), dim3(256), G::LDS_BYTES, e->stream,
-                               (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
+                               (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, cin, cout);
     } else if (H == 8 && W == 8) {
         using G = apz::WgradGeo<8, 8>;
+        if (int rc = wgrad_scratch(e, (size_t)slices * cout * cin * 9)) return rc;
         if (!e->wgrad_attr_set[1]) {
             HIP_TRY(hipFuncSetAttribute((const void*)apz::conv3x3_wgrad_kernel<8, 8>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
             e->wgrad_attr_set[1] = true;
         }
         hipLaunchKernelGGL((apz::conv3x3_wgrad_kernel<8, 8>), dim3(gx, gy, slices), dim3(256), G::LDS_BYTES, e->stream,
-                           (const float*)x_dev, (const float*)dy_dev, (float*)dw_dev, n, cin, cout);
+                           (const float*)x_dev, (const float*)dy_dev, e->wgw_scratch, n, cin, cout);
     } else {
         return fail(APZ_E_UNSUPPORTED, "conv3x3_wgrad: unsupported board size");
     }
+    // the slices' partial sums, added in index order
+    hipLaunchKernelGGL(apz::colsum_kernel, dim3((cout * cin * 9 + 63) / 64), dim3(256), 0, e->stream, (const float*)e->wgw_scratch,
+                       (float*)dw_dev, slices, cout * cin * 9, 1.0f);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }
@@ -1657,13 +1675,7 @@ int apz_wgrad_wino(apz_engine* e, const void* x_dev, const void* dy_dev, void* d
     // slice sit on one XCD (see the kernel)
     const int spx = std::max(1, std::min((n + 7) / 8, e->num_cu / (8 * T3::BLOCKS)));
     const int slices = 8 * spx;
-    if (slices > e->wgw_slices) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (e->wgw_scratch) HIP_TRY(hipFree(e->wgw_scratch));
-        e->wgw_scratch = nullptr;
-        HIP_TRY(hipMalloc((void**)&e->wgw_scratch, (size_t)slices * T::SCRATCH_FLOATS_PER_SLICE * sizeof(float)));
-        e->wgw_slices = slices;
-    }
+    if (int rc = wgrad_scratch(e, (size_t)slices * T::SCRATCH_FLOATS_PER_SLICE)) return rc;
     bool& attr = e->lds_attr_set[10];
     if (!attr) {
         HIP_TRY(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));

@@ -14,8 +14,8 @@
 // padded] in LDS; a k-step is 4 consecutive pixels: the A fragments (dY) are read once per k-step
 // and reused by the nine taps, the B fragment is the input at the tap's shift (zero halo).
 // Plane strides are odd multiples chosen so the 16 channel lanes of a fragment hit 16 distinct
-// banks.  Partial sums of the batch slices are combined with float atomics (dW is zeroed by the
-// launcher), so the summation order -- and the last bits -- vary from run to run.
+// banks.  Every batch slice writes its own partial dW; the launcher adds the slices in index order
+// (colsum_kernel): no atomics, the same bits on every run (rounds 1 - 3 used float atomics).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -513,13 +513,13 @@ struct WgradGeo {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
-// x [n][cin][H][W], dy [n][cout][H][W] dense; dw [cout][cin][3][3] (pre-zeroed, atomically added).
+// x [n][cin][H][W], dy [n][cout][H][W] dense; dw: [slices = gridDim.z][cout][cin][3][3] partial sums.
 // grid: (cout/32, ceil(cin/64), batch slices).  The staged input tile (64 channels) is shared by
 // the workgroup's two C_out tiles; a wave holds 2 x 9 accumulator tiles (72 registers).
 // Staging is software-pipelined through registers: the NEXT board's 16-byte pieces are loaded
 // before this board's MFMA loop and scattered into LDS after it, so HBM/L2 latency hides behind
 // ~1000 MFMAs per wave.  The epilogue transposes the accumulators through LDS so that every
-// atomic wave-instruction adds 64 consecutive floats of one dW row.
+// store wave-instruction writes 64 consecutive floats of one dW row.
 // R16: x and dy in the trunk's padded-row layout [n][C][15][16] (pad column zero: it adds nothing to the sums)
 template <int H, int W, bool R16 = false>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -688,10 +688,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
                 for (int r = 0; r < 4; r++) st[(c * 16 + q * 4 + r) * ROW + (wave * 16 + j) * 9 + t] = acc[c][t][r];
     }
     __syncthreads();
+    // this batch slice's partial dW (every (slice, C_out tile, C_in tile) has exactly one workgroup: plain stores);
+    // colsum_kernel (heads_train.h) adds the slices in index order -- no float atomics, the same bits on every run
     const int rowlen = nci * 9;              // valid floats of a staged row
+    float* part = dw + (size_t)blockIdx.z * cout * cin * 9;
     for (int row = wave; row < COT * 16; row += 4) {
-        float* drow = dw + ((size_t)(co0 + row) * cin + ci0) * 9;
-        for (int i = lane; i < rowlen; i += 64) atomicAdd(drow + i, st[row * ROW + i]);
+        float* drow = part + ((size_t)(co0 + row) * cin + ci0) * 9;
+        for (int i = lane; i < rowlen; i += 64) drow[i] = st[row * ROW + i];
     }
 }
 

@@ -481,6 +481,26 @@ def test_trainer_steps_match_the_comparator():
     tr.close()
 
 
+@pytest.mark.parametrize("kind,side,n,blocks", [("resnet", 15, 70, 3), ("resnet", 15, 13, 2), ("resnet", 8, 20, 2), ("simple", 8, 20, 0)])
+def test_training_steps_are_the_same_bits_on_every_run(kind, side, n, blocks):
+    """No atomics anywhere in the step (BatchNorm sums, bias gradients, both weight-gradient kernels add per-slice partial
+    sums in index order; dropout masks are a hash of (seed, step, element)): two trainers started from the same parameters
+    hold identical parameters, moments and losses after three optimiser steps (policy_value_net_mxnet.py:282-299)."""
+    from alphapig_amd.train import HipTrainer
+    prm, states, pis, zs = _problem(kind, side, n, blocks, seed=9)
+    runs = []
+    for _ in range(2):
+        tr = HipTrainer(prm, kind, n_blocks=blocks, batch_size=n, dropout=0.5, seed=5)
+        losses = [tr.train_step(states, pis, zs, 2e-3) for _ in range(3)]
+        runs.append((losses, tr.get_params(), {k: v.cpu().numpy() for k, v in tr.m.items()}))
+        tr.close()
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        np.testing.assert_array_equal(runs[0][1][k], runs[1][1][k], err_msg=k)
+    for k in runs[0][2]:
+        np.testing.assert_array_equal(runs[0][2][k], runs[1][2][k], err_msg=k)
+
+
 def test_net_train_step_updates_the_selfplay_evaluator():
     """PolicyValueNet.train_step (policy_value_net_mxnet.py:282-299): one HIP optimiser step, then the evaluator
     answers with the new weights; the loss falls over a few steps on a fixed batch."""
