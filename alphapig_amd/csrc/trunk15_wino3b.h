@@ -366,6 +366,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
 #ifndef APZB_ABL_W
 #define APZB_ABL_W 0
 #endif
+#ifndef APZB_ABL_D
+#define APZB_ABL_D 0      /* no LDS-DMA of the next chunks' planes inside the chunk loop (stale tiles: timing only) */
+#endif
 #ifndef APZB_ABL_B
 #define APZB_ABL_B 0
 #endif
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
                     if (p9 + 1 < 9 && !APZB_ABL_B) bfr[1] = *reinterpret_cast<const bf16x8*>(vp + b_lo1 + pos_off(p9 + 1)); \
                     acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][0], bfr[0], acc[p9], 0, 0, 0);            \
                     if (p9 + 1 < 9 && !APZB_ABL_B) bfr[0] = *reinterpret_cast<const bf16x8*>(vp + b_lo0 + pos_off(p9 + 1)); \
-                    if ((k) == 1) raw_dma(t, c + 2, par);                                                                \
+                    if ((k) == 1 && !APZB_ABL_D) raw_dma(t, c + 2, par);                                                 \
                     APZB_TSLICE(2 * (k))                                                                                 \
                     APZB_TSLICE(2 * (k) + 1)                                                                             \
                     /* unit k + RING - 1 goes into the ring slot of unit k - 1, whose MFMAs are done */                 \
