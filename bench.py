@@ -210,6 +210,65 @@ def bf16x3_line(device, threads, G, pipeline, mean_plies, steps=120, warmup=30):
                         "profiles/r04_winograd_numerics_bf16x3.json"}
 
 
+def train_step_line(device, steps=10, warmup=3):
+    """SURVEY 8(f1) beside the hot path: the training step that consumes the games (policy_value_net_mxnet.py:282-299), 10
+    blocks / 128 filters / 15x15, every operator a HIP kernel of this repository (alphapig_amd/train.py) -- at the reference's
+    batch size (conf/train_config.yaml: 128) and at 512.  `ms_per_step`: host arrays in, (loss, entropy) out, as the
+    reference's train_step signature has it; `ms_per_step_uploaded_batch`: on HipTrainer.upload's device copy, which is what
+    the epochs of a policy_update pay.  An EXTRA object (tools/train_bench.py is the same measurement)."""
+    import torch
+    from alphapig_amd.train import HipTrainer
+    rs = np.random.RandomState(0)
+    prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
+    out = {"net": "10 blocks x 128 filters, 15x15, fp32", "steps": steps, "warmup": warmup}
+    for B in (128, 512):
+        states = (rs.rand(B, 9, H, W) > 0.7).astype(np.float32)
+        pis = rs.dirichlet(np.ones(H * W), size=B).astype(np.float32)
+        zs = rs.choice([-1.0, 1.0], size=B).astype(np.float32)
+        tr = HipTrainer(prm, "resnet", n_blocks=N_BLOCKS, batch_size=B, device_index=device)
+        for _ in range(warmup):
+            tr.train_step(states, pis, zs, 1e-3)
+        torch.cuda.synchronize(device)
+        t = time.perf_counter()
+        for _ in range(steps):
+            tr.train_step(states, pis, zs, 1e-3)
+        torch.cuda.synchronize(device)
+        ms = 1e3 * (time.perf_counter() - t) / steps
+        batch = tr.upload(states, pis, zs)
+        tr.train_step(batch, None, None, 1e-3)
+        torch.cuda.synchronize(device)
+        t = time.perf_counter()
+        for _ in range(steps):
+            tr.train_step(batch, None, None, 1e-3)
+        torch.cuda.synchronize(device)
+        ms_up = 1e3 * (time.perf_counter() - t) / steps
+        tr.close()
+        out["batch_%d" % B] = {"ms_per_step": ms, "ms_per_step_uploaded_batch": ms_up}
+    return out
+
+
+def config2_line(device, steps=4000, warmup=50):
+    """BASELINE configs[1] (the metric's CPU-runnable sibling: 64 concurrent 8x8 games, 4 in a row, n_playout 200, the 6-conv
+    net) through the same engine: leaf evaluations per second.  An EXTRA object (tests/config_table.py is the same measurement)."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    from alphapig_amd.selfplay import SelfPlayEngine
+    prm = weights.init_params("simple", 8, 8, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
+    net = PolicyValueNet(8, 8, batch_size=32, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, net_kind="simple", device=device)
+    eng = SelfPlayEngine(net, 8, 8, 4, n_games=64, n_playout=200, temp=1.0, base_seed=77, pipeline=2, forced_opening=False)
+    eng.run_steps(warmup)
+    net.sync()
+    l0 = eng.stats["leaf_evals"]
+    t = time.perf_counter()
+    eng.run_steps(steps)
+    net.sync()
+    dt = time.perf_counter() - t
+    leafs = eng.stats["leaf_evals"] - l0
+    eng.close()
+    net.close()
+    return {"workload": "64 concurrent 8x8 games, n_in_row 4, n_playout 200, simple 6-conv net, 32-board forwards", "steps": steps,
+            "leaf_evals_per_s": leafs / dt, "ms_per_step": 1e3 * dt / steps}
+
+
 def _rank_log_dir(tag=None):
     """gpurun_out/ (travels back from the GPU box), one sub-directory per self-spawned job: two bench runs on one host
     must not truncate each other's rank logs, and the supervisor's silence watchdog sums the sizes of its OWN ranks' logs."""
@@ -411,7 +470,7 @@ def main():
                     help="count finished games over a steady-state window of this many seconds (continuous refill; the "
                          "window opens once every slot has finished a game or after --count-warmup-max seconds)")
     ap.add_argument("--count-warmup-max", type=float, default=420.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem and cpu_baseline")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem, latency, trunk_bf16x3, train_step, config2 and cpu_baseline")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # child of cpu_baseline()
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--profile-samples", type=int, default=20, help="... or more often, for at least this many timed forwards")
@@ -752,6 +811,8 @@ def main():
         line["roofline_stem"] = stem_roofline(local)
         line["latency"] = latency_probe(local)
         line["trunk_bf16x3"] = bf16x3_line(local, threads, G, args.pipeline, mean_plies)
+        line["train_step"] = train_step_line(local)
+        line["config2"] = config2_line(local)
         line["cpu_baseline"] = cpu_baseline(mean_plies, cores=max(1, min(16, ncpu)))
     print(json.dumps(line))
 
