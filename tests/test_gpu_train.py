@@ -60,7 +60,7 @@ def test_conv3x3_fwd_dgrad_wgrad_bias(n, ci, co, hw):
 def test_trunk_shape_in_the_padded_row_layout(n):
     """128 -> 128 at 15x15 on [n][128][15][16] tensors: the self-play path's fused Winograd kernel forward (with and
     without ReLU) and as data gradient with the skip gradient added in its epilogue; weight gradient through the
-    Winograd domain (from 64 boards) or the direct kernel; pad column zero on every output."""
+    Winograd domain (wgrad_wino3_kernel: every batch size, also slices without boards); pad column zero on every output."""
     from alphapig_amd import hipconv
     g = torch.Generator().manual_seed(900 + n)
     x = torch.randn(n, 128, 15, 15, generator=g)
