@@ -501,6 +501,23 @@ def test_training_steps_are_the_same_bits_on_every_run(kind, side, n, blocks):
         np.testing.assert_array_equal(runs[0][2][k], runs[1][2][k], err_msg=k)
 
 
+def test_uploaded_mini_batch_is_the_same_step():
+    """HipTrainer.upload: a policy_update's epochs train on one device copy of their mini-batch (train_mxnet.py:201-207 feeds
+    the same arrays to every epoch) -- the same losses and parameters as steps fed from the host arrays."""
+    from alphapig_amd.train import HipTrainer
+    prm, states, pis, zs = _problem("resnet", 15, 40, 2, seed=12)
+    a = HipTrainer(prm, "resnet", n_blocks=2, batch_size=40, dropout=0.5, seed=7)
+    b = HipTrainer(prm, "resnet", n_blocks=2, batch_size=40, dropout=0.5, seed=7)
+    batch = b.upload(states, pis, zs)
+    for _ in range(3):
+        assert a.train_step(states, pis, zs, 1e-3) == b.train_step(batch, None, None, 1e-3)
+    pa, pb = a.get_params(), b.get_params()
+    for k in pa:
+        np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
+    a.close()
+    b.close()
+
+
 def test_net_train_step_updates_the_selfplay_evaluator():
     """PolicyValueNet.train_step (policy_value_net_mxnet.py:282-299): one HIP optimiser step, then the evaluator
     answers with the new weights; the loss falls over a few steps on a fixed batch."""
