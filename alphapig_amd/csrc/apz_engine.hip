@@ -132,7 +132,6 @@ struct apz_engine {
     size_t smp_cap = 0;
     float* zeros256 = nullptr;          // bias stand-in for bias-free convolutions
     double* bn_part = nullptr;                     // apz_bn_fwd / _bwd: per-(channel, batch split) partial sums [256 * BN_SPLITS][2]
-    unsigned* tail_counters = nullptr;             // apz_bias_grad: grid_tail tickets per channel (conv_train.h), zero between launches
     float* wgw_scratch = nullptr;                  // apz_wgrad_wino: partial dU per batch slice
     double* fold_ws = nullptr;                     // apz_load_weights_dev: scale / shift of one layer (2 x 256 doubles)
     float* head_scratch = nullptr;                 // apz_conv1x1_bwd / apz_pv_loss: per-board partial sums
@@ -698,7 +697,7 @@ void apz_destroy(apz_engine* e) {
     }
     void* dev[] = {e->w6, e->b6, e->wfc_pk, e->bfc, e->wv, e->bv, e->act[0], e->act[1], e->act[2], e->planes,
                    e->featp, e->featv, e->probs, e->values, e->codes, e->perm_s, e->perm_p, e->smp_vis, e->smp_pi, e->smp_mv, e->zeros256,
-                   e->wino_scratch[0], e->wino_scratch[1], e->bn_part, e->tail_counters, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws,
+                   e->wino_scratch[0], e->wino_scratch[1], e->bn_part, e->adam_tab, e->wgw_scratch, e->head_scratch, e->fc_logits, e->fold_ws,
                    e->wfc_raw, e->w3s_slabs, e->w3s_tickets};
     for (void* p : dev)
         if (p) hipFree(p);
@@ -1793,7 +1792,7 @@ int apz_conv1x1_bwd2(apz_engine* e, const void* x_dev, const void* w1_dev, const
 }
 
 int apz_bias_grad(apz_engine* e, const void* dy_dev, void* db_dev, int n, int C, int layout, void* stream) {
-    if (!e || !dy_dev || !db_dev || n < 1 || C < 1 || C > 256) return fail(APZ_E_ARG, "bad argument");
+    if (!e || !dy_dev || !db_dev || n < 1 || C < 1) return fail(APZ_E_ARG, "bad argument");
     int ps, rs;
     if (int rc = bn_geometry(e, layout, &ps, &rs)) return rc;
     EngineLock guard(e->submit_lock);
@@ -1801,12 +1800,10 @@ int apz_bias_grad(apz_engine* e, const void* dy_dev, void* db_dev, int n, int C,
     StreamScope sc(e, stream);
     const int slices = std::max(1, std::min(n, (e->num_cu * 8 + C - 1) / C));
     if (int rc = head_scratch(e, (size_t)slices * C)) return rc;
-    if (!e->tail_counters) {
-        HIP_TRY(hipMalloc((void**)&e->tail_counters, 256 * sizeof(unsigned)));
-        HIP_TRY(hipMemset(e->tail_counters, 0, 256 * sizeof(unsigned)));
-    }
-    hipLaunchKernelGGL(apz::bias_grad_kernel, dim3(C, slices), dim3(256), 0, e->stream, (const float*)dy_dev, e->head_scratch,
-                       (float*)db_dev, e->tail_counters, n, C, ps);
+    hipLaunchKernelGGL(apz::bias_grad_kernel, dim3(C, slices), dim3(256), 0, e->stream, (const float*)dy_dev, e->head_scratch, n, C,
+                       ps);
+    hipLaunchKernelGGL(apz::colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, e->stream, (const float*)e->head_scratch,
+                       (float*)db_dev, slices, C, 1.0f);
     HIP_TRY(hipGetLastError());
     return APZ_OK;
 }

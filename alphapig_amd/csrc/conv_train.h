@@ -127,43 +127,17 @@ __global__ void rows16_to_dense_kernel(const float* __restrict__ x, float* __res
     }
 }
 
-// ---- the workgroup that draws a channel's LAST ticket finishes the channel's reduction (bias_grad_kernel,
-// heads_train.h: grid (channel, batch slice)): thread 0 of every workgroup writes its partial result with tail_store (a
-// write-through store: device-scope, visible to the other XCDs once acknowledged), waits for the acknowledgement and
-// takes a ticket from the CHANNEL's counter; the workgroup that gets the channel's last ticket reads the channel's
-// partials with tail_load (device-scope loads: past its own L1 / L2) and adds them in a fixed order.  Measured on the
-// way (profiles/r04_train_fusion.md): a device-scope release fence (`__threadfence()`) per workgroup writes back the
-// XCD's whole L2 -- 2 048 workgroups per launch took the training step from 5.0 to 15.4 ms; ONE ticket counter per
-// launch serialises 2 048 atomics on one address (+25 us per launch); and even per-channel tickets put ~5 us of
-// dependent device-scope round trips (store, acknowledge, atomic, loads) at the end of the kernel -- as much as the
-// second launch they replace.  Hence the BatchNorm kernels below do NOT use tickets: their consumers add the partials.
-// The last workgroup puts its counter back to 0: launches that share counters must be ordered by their stream.
-template <typename T>
-__device__ __forceinline__ void tail_store(T* p, T v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ T tail_load(const T* p) {
-    return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// all threads of the workgroup call; thread 0 must be the one that made the workgroup's tail_store()s
-__device__ __forceinline__ bool grid_tail(unsigned* counter, unsigned total) {
-    __shared__ unsigned tk;
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the partials have arrived before the ticket is taken
-        tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tk == total - 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    return tk == total - 1;
-}
-
 // ---- training-mode BatchNorm (+ residual, + ReLU) over [n][C][H][W] planes with plane stride PS and row
 // stride RS (dense NCHW: PS = H*W, RS = W; the trunk's padded-row layout: PS = 240, RS = 16).  Statistics are
 // over the n*H*W valid elements of a channel; pad columns (x >= W) are written as zero and never read.
 // Two launches forward, two backward, every one a grid (channel, batch split); nothing is zeroed beforehand and there
 // are no atomics (round 3: memset + statistics with double atomics + finalize + apply -- each small launch ~5 us of
-// queue time; and the sums depended on the arrival order in their last bits):
+// queue time; and the sums depended on the arrival order in their last bits).  Finishing the reduction INSIDE the
+// statistics launch (the workgroup that draws the last ticket adds the partials) was built and measured three ways --
+// a device-scope fence per workgroup writes back the XCD's whole L2 (step 5.0 -> 15.4 ms), one ticket counter per launch
+// serialises 2 048 atomics on one address (+25 us per launch), per-channel tickets with write-through stores cost ~5 us of
+// dependent device-scope round trips, as much as the launch they replace (profiles/r04_train_fusion.md) -- and dropped:
+// the CONSUMER workgroups add the partials.
 //   bn_stats_kernel      part[c][split] = (sum x, sum x^2) in double, plain stores
 //   bn_apply_kernel      every workgroup adds ITS channel's partials (<= 64 pairs of doubles, a fixed order) and derives
 //                        mean, 1/sqrt(var + eps); y = act((x - mean) * invstd * gamma + beta (+ resid)); workgroup

@@ -163,11 +163,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
                                                      float scale) {
     colsum_block(in, out, rows, cols, scale, blockIdx.x);
 }
-// part[c][s] = sum over the boards of slice s and the cells of plane c of dy[n][c][.] (planes of `ps` floats: dense, or
-// padded rows whose pad cells are zero); grid (C, slices); the channel's last workgroup (grid_tail, conv_train.h) adds
-// the slices in a fixed order: db[c].
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* part, float* db,
-                                                        unsigned* __restrict__ counter, int n, int C, int ps) {
+// part[s][c] = sum over the boards of slice s and the cells of plane c of dy[n][c][.] (planes of `ps` floats: dense, or
+// padded rows whose pad cells are zero); grid (C, slices); colsum_kernel then adds the slices in index order.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ part, int n, int C,
+                                                        int ps) {
     __shared__ double sh[4];
     const int c = blockIdx.x, slices = gridDim.y, sl = blockIdx.y;
     const int b0 = (int)((long)n * sl / slices), b1 = (int)((long)n * (sl + 1) / slices);
@@ -179,12 +178,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
         s += (double)t;
     }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) tail_store(part + (size_t)c * slices + sl, (float)s);
-    if (!grid_tail(counter + c, slices)) return;
-    s = 0.0;
-    for (int k = threadIdx.x; k < slices; k += 256) s += (double)tail_load(part + (size_t)c * slices + k);
-    s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) db[c] = (float)s;
+    if (threadIdx.x == 0) part[(size_t)sl * C + c] = (float)s;
 }
 
 // y += x
