@@ -26,7 +26,9 @@ int main() {
     const int ROT = 4;
     CK(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)apz::wgrad_wino3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
+    const int only_n = getenv("APZ_WGKB_N") ? atoi(getenv("APZ_WGKB_N")) : 0;     // (PMC runs: one batch size)
     for (int n : {64, 128, 131, 512}) {
+        if (only_n && n != only_n) continue;
         const size_t plane = (size_t)n * 128 * 240;
         std::vector<float> h(plane);
         for (size_t i = 0; i < plane; i++) h[i] = (i % 16 == 15) ? 0.f : (float)((i * 2654435761u >> 8) % 2001) / 1000.f - 1.f;
