@@ -140,18 +140,19 @@ class HipTrainer(object):
                 A, B = "A%d" % i, "B%d" % i
                 ua, ub = (upk[2 * i - 2, 0], upk[2 * i - 1, 0]) if upk is not None else (None, None)
                 sa = sb = None
-                if upk is not None:     # the Winograd kernel's epilogue leaves the BatchNorm's per-board sums: no statistics pass
+                fused = upk is not None and int(x.shape[0]) <= 16384       # (apz_wino_conv_stats: one launch)
+                if fused:               # the Winograd kernel's epilogue leaves the BatchNorm's per-board sums: no statistics pass
                     ya, sa = o.conv3x3_fwd_stats(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], upk=ua)
                 else:
-                    ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay)
+                    ya = o.conv3x3_fwd(x, p["conv" + A + "_weight"], p["conv" + A + "_bias"], lay, upk=ua)
                 wm = self.rows16        # padded rows: the ReLU decisions as a byte per four elements for the backward pass
                 ha, ma, ia, *ka = o.bn_fwd(ya, p["bn" + A + "_gamma"], p["bn" + A + "_beta"], p["bn" + A + "_moving_mean"],
                                            p["bn" + A + "_moving_var"], None, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sa,
                                            want_mask=wm)
-                if upk is not None:
+                if fused:
                     yb, sb = o.conv3x3_fwd_stats(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], upk=ub)
                 else:
-                    yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay)
+                    yb = o.conv3x3_fwd(ha, p["conv" + B + "_weight"], p["conv" + B + "_bias"], lay, upk=ub)
                 out, mb, ib, *kb = o.bn_fwd(yb, p["bn" + B + "_gamma"], p["bn" + B + "_beta"], p["bn" + B + "_moving_mean"],
                                             p["bn" + B + "_moving_var"], x, True, lay, 1.0 - BN_MOMENTUM, BN_EPS, stats=sb,
                                             want_mask=wm)
