@@ -1001,10 +1001,11 @@ int apzh_pure_get_move(apzh_pool *p, int gi, uint32_t *mt_key624, int32_t *mt_po
 
 double apzh_pretouch_limit_gb(double avail_gb, int local_world) {
     if (local_world < 1) local_world = 1;
-    // half of what is available, split between the ranks of this node; never more than 96 GB per rank, and at least
-    // 4 GB per rank as long as the ranks' floors together still fit into that half
+    // half of what is available, split between the ranks of this node, never more than 96 GB per rank.  A single rank keeps
+    // a floor of 4 GB (round 3's rule); several ranks get no floor: floors would add up past the half on a small node
     const double share = 0.5 * avail_gb / (double)local_world;
-    return std::min(96.0, std::max(std::min(4.0, share * 2.0), share));
+    const double floor_gb = local_world == 1 ? std::min(4.0, avail_gb) : 0.0;
+    return std::min(96.0, std::max(floor_gb, share));
 }
 
 int apzh_mt_seed(uint32_t seed, uint32_t *key624, int32_t *pos) {

@@ -131,6 +131,9 @@ __global__ __launch_bounds__(512) void wgrad_wino3_kernel(const float* __restric
     // staged them in LDS by LDS-DMA: that path moves 16 bytes per clock and CU -- 64 cycles per plane request whatever its
     // size --, 4 100 of a half board's 5 700 cycles, and every wave that requests blocks on it; profiles/r04_wgrad_wino3.md).
     // Input: patch rows 4 trow - 1 .. 4 trow + 4; gradient: tile rows 4 trow .. 4 trow + 3; rows off the board: zero.
+    // rows off the board: a per-lane offset past ANY legal num_records (the range check sees the per-lane offset only, not
+    // the scalar board offset; apz_wgrad_wino admits n <= 32768 boards = 0xF0000000 bytes < WGW3_OOB, and WGW3_OOB + 16 does not wrap)
+    constexpr unsigned WGW3_OOB = 0xF8000000u;
     f32x4 nx[6];
     auto prefetch = [&](int u) {
         const int uu = u < total ? u : total - 1;     // (past the end: a harmless repeat)
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(512) void wgrad_wino3_kernel(const float* __restric
             const int R = grad ? 4 * trow + i : 4 * trow - 1 + i;
             const bool in = R >= 0 && R <= 14;
             if constexpr (BUF) {
-                nx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? plane_off + (unsigned)R * 64u : 0x80000000u, soff, 0));
+                nx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? plane_off + (unsigned)R * 64u : WGW3_OOB, soff, 0));
             } else {
                 nx[i] = *reinterpret_cast<const f32x4*>(pb + (in ? R : 0) * 16);
                 if (!in) nx[i] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -42,7 +42,9 @@ Two schedules (`async_update` in the configuration; default True):
                the gathered game batches from a queue, puts them into the replay buffer, runs `policy_update` -- one per
                game batch like the reference, never more; batches that arrive while an update runs are merged into the
                next one and counted as `updates_skipped` -- saves / evaluates on the reference's schedule and publishes a
-               snapshot of the weights, which the next round broadcasts.  Staleness bound: a rank plays with weights that
+               snapshot of the weights, which the next round broadcasts.  The SGF bootstrap batches (`sgf_batches`,
+               train_mxnet.py:270-271) run on the trainer thread first, one record + one update per batch, while the ranks
+               already self-play; they count as game batches.  Staleness bound: a rank plays with weights that
                are at most (one round + one policy_update + one broadcast) older than the trainer's; the switch can fall
                inside a game, as in lock step.  `max_update_share` < 1 makes the trainer pause after an update so that it
                is busy at most that share of the time (on ONE GPU self-play and training share the device: the
@@ -324,13 +326,17 @@ class TrainPipeline(object):
             if time.perf_counter() >= t_end:
                 return
 
-    def _schedule_after_batch(self, i, rec, net):
+    def _schedule_after_batch(self, i, rec, net, first=None):
         """The reference's per-batch schedule behind the update (train_mxnet.py:283-298): checkpoint every 50 batches,
-        arena every check_freq.  i = 0-based game-batch index."""
-        if (i + 1) % 50 == 0:
+        arena every check_freq.  i = 0-based game-batch index.  `first` (asynchronous schedule): the update covered the
+        game batches first ... i (a cluster of games finished in one round); the weights are the same for all of them, so a
+        checkpoint / an arena evaluation runs ONCE if the range crosses a multiple, not once per skipped index."""
+        lo = i if first is None else first
+        crosses = lambda m: (i + 1) // m > lo // m          # some k in (lo, i + 1] is a multiple of m
+        if crosses(50):
             os.makedirs(self.model_dir, exist_ok=True)
             net.save_model(os.path.join(self.model_dir, "current_policy.model"))
-        if (i + 1) % self.check_freq == 0:
+        if crosses(self.check_freq):
             rec["win_ratio"] = wr = self.policy_evaluate(net=net)
             if wr > self.best_win_ratio:
                 self.best_win_ratio = wr
@@ -365,9 +371,30 @@ class TrainPipeline(object):
                     trainer = HipTrainer(net.params(), net.net_kind, net._n_blocks, batch_size=self.batch_size,
                                          device_index=net._device, seed=self._seed)
                 self._async_trainer = trainer
-                games_recv = batches_done = 0
+                games_recv = 0
                 busy_until = 0.0
                 stop = False
+                # SGF bootstrap (train_mxnet.py:270-271: the first batches replay game records instead of searching):
+                # game batches 0 ... n_sgf - 1, one record + one policy_update each, here on the trainer thread while the
+                # ranks already self-play; what they finish meanwhile waits in the queue and joins the buffer afterwards
+                n_sgf = self._sgf_phase_batches()
+                for i in range(n_sgf):
+                    self.collect_selfplay_data(i)
+                    rec = {"batch": i + 1, "sgf": True, "episode_len": self.episode_len, "buffer": len(self.data_buffer)}
+                    if len(self.data_buffer) > self.batch_size:
+                        t0 = time.time()
+                        loss, entropy, kl = self.policy_update(trainer, kl_net)
+                        snap = self._snapshot(trainer)
+                        self.update_intervals.append((t0, time.time()))
+                        with self._lock:
+                            self.updates_done += 1
+                            self._last = (loss, entropy, kl)
+                            self._fresh = (self.updates_done, snap)
+                        rec.update(loss=loss, entropy=entropy, kl=kl)
+                    self._schedule_after_batch(i, rec, kl_net)
+                    with self._lock:
+                        self.trainer_history.append(rec)
+                batches_done = n_sgf
                 while not stop:
                     items = [self._train_q.get()]
                     while True:
@@ -383,7 +410,7 @@ class TrainPipeline(object):
                         states = self.engine.pool.codes_to_planes(codes, 9)
                         self.data_buffer.extend(get_equi_data(list(zip(states, pis, zs)), self.board_height, self.board_width))
                         games_recv += n_games
-                    due = games_recv // self.play_batch_size - batches_done
+                    due = n_sgf + games_recv // self.play_batch_size - batches_done
                     if due <= 0:
                         continue
                     first = batches_done
@@ -406,12 +433,15 @@ class TrainPipeline(object):
                             self._last = (loss, entropy, kl)
                             self._fresh = (self.updates_done, snap)
                         rec.update(loss=loss, entropy=entropy, kl=kl)
-                    for i in range(first, batches_done):
-                        self._schedule_after_batch(i, rec, kl_net)
+                    self._schedule_after_batch(batches_done - 1, rec, kl_net, first=first)
                     with self._lock:
                         self.trainer_history.append(rec)
         except BaseException as e:          # surfaces in the main thread at the next round
             self._trainer_error = e
+
+    def _sgf_phase_batches(self):
+        """How many leading game batches replay SGF records (0 without records), never more than game_batch_num."""
+        return min(int(self.sgf_batches), int(self.game_batch_num)) if self._training_data else 0
 
     def _snapshot(self, trainer):
         """A private copy of the trainer's weights for the main thread to broadcast / load while the trainer goes on."""
@@ -439,7 +469,8 @@ class TrainPipeline(object):
 
     def _run_async(self):
         lead = self.rank == 0
-        target_games = self.game_batch_num * self.play_batch_size * self.world
+        # the SGF bootstrap batches (rank 0's trainer thread) count as game batches, like the reference's loop index
+        target_games = (self.game_batch_num - self._sgf_phase_batches()) * self.play_batch_size * self.world
         self.trainer_history = []
         self._games_collected = 0
         if lead:
@@ -470,26 +501,29 @@ class TrainPipeline(object):
             self.last_gathered = n_games
             head = [0.0] * 9
             fresh = None
+            failed = False
             if lead:
-                if self._trainer_error is not None:
-                    raise RuntimeError("the trainer thread died") from self._trainer_error
                 self._games_collected += n_games
-                if len(zs):
+                if len(zs) and self._trainer_error is None:
                     self._train_q.put((codes, pis, zs, n_games))
                 done = self._games_collected >= target_games
-                if done:                                # drain: the only time anybody waits for the trainer
+                if done and self._trainer_error is None:        # drain: the only time anybody waits for the trainer
                     self._train_q.put(None)
                     self._trainer_thread.join()
-                    if self._trainer_error is not None:
-                        raise RuntimeError("the trainer thread died") from self._trainer_error
+                failed = self._trainer_error is not None        # travels in the header: every rank leaves the loop together
                 with self._lock:
                     fresh, self._fresh = self._fresh, None
                     loss, entropy, kl = self._last
                     head = [1.0 if done else 0.0, float(fresh[0]) if fresh else float(self.weights_version),
                             float(self.updates_done), loss, entropy, kl, self.lr_multiplier, float(self._games_collected),
                             float(self.updates_skipped)]
+                if failed:
+                    head[0] = -1.0
             if self.distributed:
                 head = dist.broadcast_floats(head, src=0)
+            if head[0] < 0.0:
+                # rank 0 raises with the cause; the others raise too instead of blocking in the next collective
+                raise RuntimeError("the trainer thread died on rank 0") from (self._trainer_error if lead else None)
             version = int(head[1])
             rec = {"round": rnd, "games": n_games, "games_collected": int(head[7]), "version": version,
                    "updates": int(head[2]), "updates_skipped": int(head[8]), "leaf_evals": int(self.engine.stats["leaf_evals"])}

@@ -145,7 +145,11 @@ class PolicyValueNet(object):
     def save_model(self, model_file, fmt="mxnet"):
         """fmt 'mxnet' (default): the reference's file -- pickle protocol 2 of (arg_params, aux_params) dicts of
         mx.nd.NDArray (policy_value_net_mxnet.py:305-309), which human_play_mxnet.py / train_mxnet.py's
-        init_model read with set_params(*model_params).  fmt 'flat': a plain {name: ndarray} pickle.
+        init_model read with set_params(*model_params).  FORMAT UNVERIFIED: no sample .model file exists in the
+        reference tree and MXNet is not installable here, so the NDArray byte layout is restated from the MXNet 1.x
+        sources and has only been round-tripped through this package's own reader (alphapig_amd/mxnet_model.py,
+        tests/test_mxnet_model.py); a file written here has never been opened by MXNet.  fmt 'flat': a plain
+        {name: ndarray} pickle -- the format to use when nothing but this package has to read the file.
         weights.load_params reads both."""
         if fmt == "mxnet":
             from . import mxnet_model

@@ -271,8 +271,9 @@ def config2_line(device, steps=4000, warmup=50):
 
 def _rank_log_dir(tag=None):
     """gpurun_out/ (travels back from the GPU box), one sub-directory per self-spawned job: two bench runs on one host
-    must not truncate each other's rank logs, and the supervisor's silence watchdog sums the sizes of its OWN ranks' logs."""
-    d = os.path.join(REPO, "gpurun_out")
+    must not truncate each other's rank logs, and the supervisor's silence watchdog sums the sizes of its OWN ranks' logs.
+    APZ_RANK_LOG_DIR moves the parent directory (the test-suite points it at pytest's tmp_path: tests/conftest.py)."""
+    d = os.environ.get("APZ_RANK_LOG_DIR") or os.path.join(REPO, "gpurun_out")
     if tag is not None:
         d = os.path.join(d, "ranks_%s" % tag)
     try:

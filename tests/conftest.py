@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _rank_logs_in_tmp(tmp_path_factory):
+    """bench.py's self-spawned ranks log under gpurun_out/ by default (it travels back from the GPU box); under pytest the
+    logs go to a session tmp dir so that the suite leaves nothing behind in the tree."""
+    old = os.environ.get("APZ_RANK_LOG_DIR")
+    os.environ["APZ_RANK_LOG_DIR"] = str(tmp_path_factory.mktemp("rank_logs"))
+    yield
+    if old is None:
+        os.environ.pop("APZ_RANK_LOG_DIR", None)
+    else:
+        os.environ["APZ_RANK_LOG_DIR"] = old
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -122,7 +122,7 @@ def test_pretouch_limit_is_shared_between_the_ranks_of_a_node():
     round 3's rule (half of the memory, at most 96 GB, at least 4)."""
     f = _native.host().apzh_pretouch_limit_gb
     assert f(2000.0, 1) == 96.0 and f(64.0, 1) == 32.0 and f(6.0, 1) == 4.0
-    for avail in (64.0, 512.0, 1500.0, 2000.0):
+    for avail in (8.0, 16.0, 64.0, 512.0, 1500.0, 2000.0):
         assert 8 * f(avail, 8) <= 0.5 * avail + 1e-9
     assert f(2000.0, 8) >= 31.0 and f(1500.0, 8) >= 31.0
     assert f(512.0, 8) == 32.0 and f(64.0, 8) == 4.0 and f(2000.0, 0) == 96.0

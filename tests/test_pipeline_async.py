@@ -1,0 +1,99 @@
+"""The asynchronous schedule's rank-0 side in ONE process (no process group): the SGF bootstrap phase
+(train_mxnet.py:270-271: the first batches replay game records), the once-per-update checkpoint / arena schedule
+(train_mxnet.py:283-298) and a trainer thread that dies.  Stand-in evaluator and trainer (tests/_pipeline_worker.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from _pipeline_worker import TiltNet, TiltTrainer
+from alphapig_amd.pipeline import TrainPipeline
+
+
+def _conf(tmp_path, **kw):
+    c = {"board_width": 15, "board_height": 15, "n_in_row": 5, "learn_rate": 2e-3, "lr_multiplier": 1.0, "temp": 1.0,
+         "n_playout": 6, "c_puct": 5, "buffer_size": 100000, "batch_size": 16, "epochs": 1, "kl_targ": 1e9,
+         "check_freq": 1000, "eval_games": 2, "game_batch_num": 6, "play_batch_size": 1, "pure_mcts_playout_num": 10,
+         "async_update": True, "round_steps": 8, "concurrent_games": 4, "model_dir": str(tmp_path / "models")}
+    c.update(kw)
+    return c
+
+
+def _sgf_dir(golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "sgf.npz"))
+    d = tmp_path / "sgf"
+    d.mkdir()
+    good = 0
+    for k in range(int(g["n"])):
+        if int(g["f%d_warning" % k]):
+            continue
+        with open(d / str(g["f%d_name" % k]), "w", newline="") as f:
+            f.write(str(g["f%d_text" % k]))
+        good += 1
+    return str(d), good
+
+
+def test_async_schedule_runs_the_sgf_bootstrap_batches_first(golden_dir, tmp_path):
+    sgf_home, good = _sgf_dir(golden_dir, tmp_path)
+    assert good >= 2
+    net = TiltNet(225)
+    trainer = TiltTrainer(net)
+    pipe = TrainPipeline(_conf(tmp_path, sgf_batches=4, sgf_dir=sgf_home), policy_value_net=net, seed=3, trainer=trainer,
+                         eval_net=TiltNet(225), distributed=False)
+    hist = pipe.run()
+    th = pipe.trainer_history
+    sgf_recs = [r for r in th if r.get("sgf")]
+    # game batches 1 ... 4 are SGF records, in order, each followed by an update once the buffer holds a mini-batch
+    assert [r["batch"] for r in sgf_recs] == [1, 2, 3, 4] and th[:4] == sgf_recs
+    assert all(r["episode_len"] > 0 for r in sgf_recs) and sgf_recs[0]["buffer"] == 8 * sgf_recs[0]["episode_len"]
+    assert all("loss" in r for r in sgf_recs[1:])          # (a two-move record alone does not fill a mini-batch of 16)
+    # ... and count as game batches: only game_batch_num - sgf_batches = 2 self-play games are waited for
+    assert hist[-1]["games_collected"] >= 2 and pipe.updates_done >= 3
+    assert [r["batch"] for r in th if not r.get("sgf")][-1] == 4 + hist[-1]["games_collected"]
+    assert pipe.weights_version == pipe.updates_done                     # the self-play evaluator ended on the last snapshot
+    np.testing.assert_array_equal(net.params()["w"], trainer.get_params()["w"])
+    pipe.engine.close()
+
+
+def test_async_schedule_without_records_skips_the_phase(tmp_path):
+    net = TiltNet(225)
+    pipe = TrainPipeline(_conf(tmp_path, sgf_batches=4, sgf_dir=str(tmp_path / "nowhere"), game_batch_num=2),
+                         policy_value_net=net, seed=3, trainer=TiltTrainer(net), eval_net=TiltNet(225), distributed=False)
+    hist = pipe.run()
+    assert not any(r.get("sgf") for r in pipe.trainer_history) and hist[-1]["games_collected"] >= 2
+    pipe.engine.close()
+
+
+def test_schedule_runs_once_per_update_when_an_update_covers_several_batches(tmp_path):
+    net = TiltNet(225)
+    pipe = TrainPipeline(_conf(tmp_path, check_freq=3), policy_value_net=net, seed=3, trainer=TiltTrainer(net),
+                         distributed=False)
+    calls = {"save": 0, "arena": 0}
+    pipe.policy_evaluate = lambda n_games=None, net=None: calls.__setitem__("arena", calls["arena"] + 1) or 0.0
+
+    class _Net(object):
+        def save_model(self, path):
+            calls["save"] += 1
+    # one update that covers the game batches 45 ... 104 (0-based): multiples of 50 and of 3 are crossed many times
+    pipe._schedule_after_batch(104, {}, _Net(), first=45)
+    assert calls == {"save": 1, "arena": 1}
+    pipe._schedule_after_batch(105, {}, _Net(), first=105)                # batch 106: no multiple of 50, no multiple of 3
+    assert calls == {"save": 1, "arena": 1}
+    pipe._schedule_after_batch(107, {}, _Net())                            # lock-step form: batch 108 = 36 * 3
+    assert calls == {"save": 1, "arena": 2}
+    pipe._schedule_after_batch(149, {}, _Net(), first=149)                # batch 150
+    assert calls == {"save": 2, "arena": 3}
+    pipe.engine.close()
+
+
+def test_a_dead_trainer_thread_ends_the_run_with_its_cause(tmp_path):
+    class Boom(TiltTrainer):
+        def train_step(self, *a):
+            raise ValueError("boom")
+    net = TiltNet(225)
+    pipe = TrainPipeline(_conf(tmp_path, game_batch_num=50), policy_value_net=net, seed=3, trainer=Boom(net),
+                         eval_net=TiltNet(225), distributed=False)
+    with pytest.raises(RuntimeError, match="trainer thread died") as ei:
+        pipe.run()
+    assert isinstance(ei.value.__cause__, ValueError)
+    pipe.engine.close()
