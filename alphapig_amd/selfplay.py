@@ -98,6 +98,10 @@ class SelfPlayEngine(object):
         self.stats = collections.Counter()
         self.timers = collections.Counter()
         self.step_times = None          # bench.py sets a list: wall time of every scheduler round lands there
+        # optional observer callable(slot_ids, codes, probs, values), called once per evaluated batch right before the
+        # outputs are fed to the trees: which slot asked for which position and what the evaluator answered (the parity
+        # tests record the games they replay through the sequential oracle with it; None costs nothing)
+        self.tap = None
         self._limit = None
         n_workers = min(self.pipeline, getattr(self.evaluator, "n_slots", 1)) if self._slotted else 1
         # one worker thread per slot; a worker serves its own groups in order
@@ -285,11 +289,11 @@ class SelfPlayEngine(object):
             t0 = time.perf_counter()
             n = self.evaluator.submit_codes_slot(slot, codes)
             self.timers["eval_s"] += time.perf_counter() - t0
-            return ("slot", slot, n, ids)
+            return ("slot", slot, n, ids, codes)
         if self._exec is not None:
             w = gi % len(self._exec)
-            return ("future", self._exec[w].submit(self._evaluate, codes, w), ids)
-        return ("done", self._evaluate(codes), ids)
+            return ("future", self._exec[w].submit(self._evaluate, codes, w), ids, codes)
+        return ("done", self._evaluate(codes), ids, codes)
 
     def _collect(self, ticket):
         """-> (probs, values, ids) of a dispatched group (blocks until the GPU is done with it)."""
@@ -297,11 +301,15 @@ class SelfPlayEngine(object):
             t0 = time.perf_counter()
             p, v = self.evaluator.wait_slot(ticket[1], ticket[2])
             self.timers["eval_s"] += time.perf_counter() - t0
-            return p, v, ticket[3]
-        if ticket[0] == "future":
+            ids = ticket[3]
+        elif ticket[0] == "future":
             p, v = ticket[1].result()
-            return p, v, ticket[2]
-        return ticket[1][0], ticket[1][1], ticket[2]
+            ids = ticket[2]
+        else:
+            (p, v), ids = ticket[1], ticket[2]
+        if self.tap is not None:
+            self.tap(ids, ticket[-1], p, v)
+        return p, v, ids
 
     def _groups(self):
         return [list(range(g, self.G, self.pipeline)) for g in range(self.pipeline)]

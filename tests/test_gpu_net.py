@@ -81,11 +81,12 @@ def test_resnet_layers_and_heads(resnet3, n):
     np.testing.assert_allclose(net.layer_output(6, n), o_trunk, rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("kind", ["wino3", "wino3-batched"])
+@pytest.mark.parametrize("kind", ["wino3", "wino3-batched", "wino3b"])
 def test_resnet_full_depth_10_blocks(kind):
-    """The 10-block net (train_mxnet.py:79-91) against the float64 oracle on BOTH fp32 Winograd trunk kernels: 24 boards
+    """The 10-block net (train_mxnet.py:79-91) against the float64 oracle on every Winograd trunk kernel: 24 boards
     take trunk15_wino3s_kernel by default ("wino3"); "wino3-batched" forces trunk15_wino3_kernel, the kernel the
-    self-play bench spends 97 % of its GPU time in, onto the same batch."""
+    self-play bench spends 97 % of its GPU time in, onto the same batch; "wino3b" = trunk_arith "bf16x3", the 3 x bf16
+    split kernel forced onto it."""
     prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
     net = _net_with_trunk_kernel(kind, prm, 10, 32)
     _, planes = random_positions(24, 15, seed=7)

@@ -58,7 +58,7 @@ class Never(object):
         return 1.0
 
 
-@pytest.mark.parametrize("cfg", ["simple8", "resnet15"])
+@pytest.mark.parametrize("cfg", ["simple8", "resnet15", "resnet15-bf16x3"])
 def test_engine_on_gpu_equals_sequential_oracle_on_recorded_outputs(cfg):
     from alphapig_amd.policy_value_net import PolicyValueNet
     if cfg == "simple8":      # BASELINE config 2 shape: 8x8, 4-in-row, simple net
@@ -66,10 +66,15 @@ def test_engine_on_gpu_equals_sequential_oracle_on_recorded_outputs(cfg):
         prm = weights.init_params("simple", 8, 8, 9, seed=1, style="bench")
         net = PolicyValueNet(8, 8, batch_size=64, model_params=prm, net_kind="simple")
         forced = False
-    else:                     # BASELINE config 3 shape: 15x15, 5-in-row, residual net
+    elif cfg == "resnet15":   # BASELINE config 3 shape: 15x15, 5-in-row, residual net
         w, nrow, npl, G, total = 15, 5, 24, 12, 12
         prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=2, style="bench")
         net = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=prm)
+        forced = True
+    else:                     # ... on the 3 x bf16 split trunk: 80 concurrent games = 40-board batches (the split kernel takes batches > 32)
+        w, nrow, npl, G, total = 15, 5, 24, 80, 80
+        prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=2, style="bench")
+        net = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=prm, trunk_arith="bf16x3")
         forced = True
     rec = Recorder(net)
     eng = SelfPlayEngine(rec, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=31337, n_threads=4,
@@ -95,6 +100,63 @@ def test_engine_on_gpu_equals_sequential_oracle_on_recorded_outputs(cfg):
     o = net_ref.forward(prm, planes, kind, 2, np.float64)
     np.testing.assert_allclose(np.stack([rec.table[k][0] for k in keys]), o[1], rtol=0, atol=2e-5)
     np.testing.assert_allclose(np.array([rec.table[k][1] for k in keys]), o[3][:, 0], rtol=0, atol=2e-5)
+    eng.close()
+    net.close()
+
+
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_full_configuration_engine_equals_sequential_oracle(arith):
+    """BASELINE configs[2] EXACTLY -- 15x15, five in a row, n_playout = 400, c_puct 5, temp 1.0, Dirichlet 0.3 / 0.25, the
+    10-block / 128-filter residual net (train_mxnet.py:79-91), the forced-opening branch live (game_ai.py:79-111) -- on the
+    HIP evaluator, on both trunk arithmetics, against the sequential oracle (mcts_alphaZero.py:141-157, :187-218 and
+    game_ai.py:70-139 restated in oracle/mcts_ref.py / selfplay_ref.py, pinned to the reference's own traces on CPU).
+    96 concurrent games = 48-board batches, i.e. the BATCHED trunk kernels (trunk15_wino3_kernel / trunk15_wino3b_kernel;
+    a board's bits do not depend on the launch shape: tests/test_gpu_net.py).  Game 0 opens freely, game 1 takes the
+    forced opening (base seed chosen for that).  Every evaluation those two games consumed is recorded (engine tap) and
+    replayed into the oracle: moves, winner and z exact, pi to 1e-12; a 64-row sample of the recorded outputs against the
+    float64 net oracle at 2e-5."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    base, G, npl = 1018, 96, 400
+    assert [random.Random(base + k).random() < 0.09 for k in (0, 1)] == [False, True]
+    prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
+    net = PolicyValueNet(15, 15, batch_size=64, n_blocks=10, n_filter=128, model_params=prm, trunk_arith=arith)
+    eng = SelfPlayEngine(net, 15, 15, 5, n_games=G, n_playout=npl, c_puct=5, temp=1.0, base_seed=base, n_threads=4,
+                         pipeline=2, forced_opening=True)
+    chosen, table, batch_sizes = (0, 1), {}, set()
+
+    def tap(ids, codes, p, v):
+        batch_sizes.add(len(ids))
+        for i, s in enumerate(ids):
+            if eng.slots[int(s)].index in chosen:
+                table[codes[i].tobytes()] = (p[i].copy(), np.float32(v[i]))
+    eng.tap = tap
+    steps = 0
+    while not set(chosen) <= set(e.index for e in eng.finished):
+        eng.run_steps(400)
+        steps += 400
+        assert steps <= 226 * 400, "a 15x15 game ends within 225 plies"
+    assert batch_sizes == {G // 2}                       # every forward was a 48-board batch: the batched kernels
+    eps = {e.index: e for e in eng.finished}
+    assert eng.stats["forced_openings"] >= 1
+    fn = replay_fn(table, eng.pool.code_stride)
+    for k in chosen:
+        e = eps[k]
+        b = RefBoard(15, 15, 5)
+        pl = RefMCTSPlayer(fn, c_puct=5, n_playout=npl, is_selfplay=1, rng=np.random.RandomState(base + k))
+        winner, data = selfplay_ref.start_self_play(b, pl, temp=1.0, pyrandom=random.Random(base + k))
+        assert winner == e.winner
+        np.testing.assert_array_equal(np.array(b.move_list), e.moves)
+        np.testing.assert_allclose(np.stack([d[1] for d in data]), e.pis, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(np.array([d[2] for d in data]), e.zs)
+        if k == 1:                                       # the forced opening: two recorded plies with the one-hot pi
+            assert e.pis[0].max() == 0.99999 and e.pis[1].max() == 0.99999
+    keys = [list(table.keys())[i] for i in np.random.RandomState(5).permutation(len(table))[:64]]
+    codes = np.stack([np.frombuffer(k, dtype=np.uint8) for k in keys])
+    o = net_ref.forward(prm, eng.pool.codes_to_planes(codes, 9), "resnet", 10, np.float64)
+    np.testing.assert_allclose(np.stack([table[k][0] for k in keys]), o[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.array([table[k][1] for k in keys]), o[3][:, 0], rtol=0, atol=2e-5)
+    print("full configuration [%s]: games 0 / 1 = %d / %d plies, %d recorded evaluations, %d engine steps"
+          % (arith, len(eps[0].moves), len(eps[1].moves), len(table), steps))
     eng.close()
     net.close()
 
