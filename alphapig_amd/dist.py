@@ -187,12 +187,18 @@ def broadcast_floats(values, src=0):
     return [float(v) for v in t.cpu()]
 
 
-def all_gather_tuples(codes, pis, zs, consumer=None):
+last_gather_stats = None   # all_gather_tuples(timing=True): where the time of the last exchange went (bench.py's `exchange`)
+
+
+def all_gather_tuples(codes, pis, zs, consumer=None, timing=False):
     """codes uint8 [T, S], pis float32 [T, HW], zs float32 [T] of this rank ->
     the concatenation over ranks in rank order (every rank gets everything).
     Variable T per rank: counts are gathered first, payloads are padded to max T.
     consumer = r: only rank r needs the result (the training pipeline's replay buffer lives on rank 0): the other
-    ranks take part in the collective but skip the device -> host copy and the unpacking and get empty arrays."""
+    ranks take part in the collective but skip the device -> host copy and the unpacking and get empty arrays.
+    timing = True: the phases are bracketed by device synchronisations and their wall times land in
+    `last_gather_stats` (a measurement mode: the product path never waits for the collective on non-consumers)."""
+    import time
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     pis = np.ascontiguousarray(pis, dtype=np.float32)
     zs = np.ascontiguousarray(zs, dtype=np.float32).reshape(-1)
@@ -204,30 +210,107 @@ def all_gather_tuples(codes, pis, zs, consumer=None):
         return codes, pis, zs
     world = dist.get_world_size()
     dev = _device()
+
+    def mark():
+        if timing and dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        return time.perf_counter()
+    t_start = mark()
     T, S, HW = codes.shape[0], codes.shape[1], pis.shape[1]
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([T], dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, mine)
     counts = counts.cpu().numpy()
-    global last_gather_total
+    global last_gather_total, last_gather_stats
     last_gather_total = int(counts.sum())            # tuples in the exchange, on every rank (also on non-consumers)
     tmax = int(counts.max())
     if tmax == 0:
+        last_gather_stats = None
         return codes[:0], pis[:0], zs[:0]
-    # one byte buffer per tuple: [codes | pi (f32) | z (f32)]
+    t_counts = mark()
+    # one byte buffer per rank, three contiguous sections padded to tmax rows each: [pi (f32) | z (f32) | codes] -- the
+    # float sections first (4-byte aligned whatever S is); packing and unpacking are plain block copies (a row-interleaved
+    # layout cost 0.86 s to unpack per 80 MB on the consumer)
     row = S + 4 * HW + 4
-    buf = np.zeros((tmax, row), dtype=np.uint8)
-    buf[:T, :S] = codes
-    buf[:T, S:S + 4 * HW] = pis.view(np.uint8).reshape(T, 4 * HW)
-    buf[:T, S + 4 * HW:] = zs.view(np.uint8).reshape(T, 4)
+    o_z, o_c = tmax * 4 * HW, tmax * (4 * HW + 4)
+    buf = np.zeros(tmax * row, dtype=np.uint8)
+    buf[:T * 4 * HW] = pis.reshape(-1).view(np.uint8)
+    buf[o_z:o_z + 4 * T] = zs.view(np.uint8)
+    buf[o_c:o_c + T * S] = codes.reshape(-1)
+    t_pack = mark()
     send = torch.from_numpy(buf).to(dev)
-    recv = torch.empty((world * tmax, row), dtype=torch.uint8, device=dev)
+    recv = torch.empty(world * tmax * row, dtype=torch.uint8, device=dev)
+    t_h2d = mark()
     dist.all_gather_into_tensor(recv, send)
+    t_coll = mark()
+    if timing:
+        last_gather_stats = {"rows_per_rank": [int(c) for c in counts], "row_bytes": int(row),
+                             "bytes_sent_per_rank": int(tmax) * int(row), "bytes_gathered": int(world) * int(tmax) * int(row),
+                             "counts_ms": 1e3 * (t_counts - t_start), "pack_ms": 1e3 * (t_pack - t_counts),
+                             "h2d_ms": 1e3 * (t_h2d - t_pack), "collective_ms": 1e3 * (t_coll - t_h2d), "d2h_unpack_ms": 0.0,
+                             "backend": str(dist.get_backend()), "world_size": int(world)}
     if consumer is not None and dist.get_rank() != int(consumer):
         return codes[:0], pis[:0], zs[:0]
-    out = recv.cpu().numpy().reshape(world, tmax, row)
-    keep = np.concatenate([out[r, :counts[r]] for r in range(world)])
-    g_codes = np.ascontiguousarray(keep[:, :S])
-    g_pis = np.ascontiguousarray(keep[:, S:S + 4 * HW]).view(np.float32).reshape(-1, HW)
-    g_zs = np.ascontiguousarray(keep[:, S + 4 * HW:]).view(np.float32).reshape(-1)
+    out = recv.cpu().numpy().reshape(world, tmax * row)
+    g_pis = np.concatenate([out[r, :counts[r] * 4 * HW] for r in range(world)]).view(np.float32).reshape(-1, HW)
+    g_zs = np.concatenate([out[r, o_z:o_z + 4 * counts[r]] for r in range(world)]).view(np.float32).reshape(-1)
+    g_codes = np.concatenate([out[r, o_c:o_c + counts[r] * S] for r in range(world)]).reshape(-1, S)
+    if timing:
+        last_gather_stats["d2h_unpack_ms"] = 1e3 * (time.perf_counter() - t_coll)
     return g_codes, g_pis, g_zs
+
+
+def synthetic_round_payload(rows, code_stride=240, hw=225, seed=0):
+    """A full round's (codes, pi, z) rows of the shape self-play produces -- position codes 0 ... 8 + the colour byte,
+    a normalised pi, z in {-1, 0, 1} -- for measuring the exchange without playing the round (bench.py's `exchange`)."""
+    rs = np.random.RandomState(seed)
+    codes = rs.randint(0, 9, size=(rows, code_stride)).astype(np.uint8)
+    codes[:, hw:] = 0
+    codes[:, hw] = rs.randint(0, 2, size=rows)
+    pis = rs.rand(rows, hw).astype(np.float32)
+    pis /= pis.sum(axis=1, keepdims=True)
+    zs = rs.randint(-1, 2, size=rows).astype(np.float32)
+    return codes, pis, zs
+
+
+def measure_exchange(rows, code_stride=240, hw=225, repeats=3, seed=0, consumer=None):
+    """Time `all_gather_tuples` on a synthetic full-round payload of `rows` rows per rank (this rank's rows are seeded
+    by its rank): one untimed call, then `repeats` timed ones between barriers; -> dict for the bench line (whole-call
+    wall time as the MAX over ranks, the collective alone, bytes, GB/s), or None without a process group.  The gathered
+    rows are checked against what every rank must have sent (regenerated from the seeds)."""
+    import time
+    if not _ACTIVE:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    codes, pis, zs = synthetic_round_payload(rows, code_stride, hw, seed + rank)
+    wall, coll, stats = [], [], None
+    for it in range(repeats + 1):
+        barrier()
+        t0 = time.perf_counter()
+        g = all_gather_tuples(codes, pis, zs, consumer=consumer, timing=True)
+        dt = all_reduce_max(time.perf_counter() - t0)
+        if it:
+            wall.append(dt)
+            coll.append(all_reduce_max(last_gather_stats["collective_ms"]))
+            stats = dict(last_gather_stats)
+    ok = True
+    if consumer is None or rank == consumer:
+        ok = g[0].shape[0] == rows * world
+        for r in range(world) if ok else ():
+            c, p, z = (codes, pis, zs) if r == rank else synthetic_round_payload(rows, code_stride, hw, seed + r)
+            sl = slice(r * rows, (r + 1) * rows)
+            ok = ok and np.array_equal(g[0][sl], c) and np.array_equal(g[1][sl], p) and np.array_equal(g[2][sl], z)
+    ok = all_reduce_sum(0.0 if ok else 1.0) == 0.0
+    ms, cms = 1e3 * float(np.median(wall)), float(np.median(coll))
+    return {"what": "one dist.all_gather_tuples of a full round's (codes | pi | z) rows per rank, synthetic rows, outside the "
+                    "timed region; every rank's rows checked on arrival",
+            "rows_per_rank": int(rows), "row_bytes": stats["row_bytes"], "bytes_sent_per_rank": stats["bytes_sent_per_rank"],
+            "bytes_gathered_per_rank": stats["bytes_gathered"], "ms": ms, "collective_ms": cms,
+            "GB_per_s_collective": stats["bytes_gathered"] / (cms * 1e-3) / 1e9 if cms > 0 else None,
+            "GB_per_s_whole_call": stats["bytes_gathered"] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "phases_ms_rank0": {k: stats[k] for k in ("counts_ms", "pack_ms", "h2d_ms", "collective_ms", "d2h_unpack_ms")},
+            "backend": stats["backend"], "ranks_seen": int(round(all_reduce_sum(1))), "repeats": int(repeats),
+            "payload_verified": bool(ok)}

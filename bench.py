@@ -128,6 +128,27 @@ def cpu_baseline(mean_plies, cores, budget_s=15.0):
                       "%.0f s each; games/s = leaf-evals/s / (400 * mean plies)" % (total_n, len(rates), isa, budget_s)}
 
 
+def exchange_probe_world1(rows, timeout_s=180.0):
+    """The N = 1 line's `exchange`: the same dist.measure_exchange as the N > 1 line runs inline, in a child process that
+    forms a process group of one rank (RCCL on the GPU box) -- a child so that a backend that fails to come up costs
+    this object, not the line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-probe", str(int(rows))], env=env, cwd=REPO,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        obj = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        obj["process"] = "child process, process group of one rank"
+        return obj
+    except Exception as e:            # noqa: BLE001 -- reported on the line
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
 def stem_roofline(device):
     """north_star target kernel: batched stem conv at 8192 x C_in x 15 x 15 (HBM-bound shape)."""
     from alphapig_amd.policy_value_net import PolicyValueNet
@@ -473,6 +494,7 @@ def main():
     ap.add_argument("--count-warmup-max", type=float, default=420.0)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem, latency, trunk_bf16x3, train_step, config2 and cpu_baseline")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # child of cpu_baseline()
+    ap.add_argument("--exchange-probe", type=int, default=0, metavar="ROWS", help=argparse.SUPPRESS)   # child of exchange_probe_world1()
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--profile-samples", type=int, default=20, help="... or more often, for at least this many timed forwards")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
@@ -500,6 +522,10 @@ def main():
         print(json.dumps({"n": n_, "dt": dt_, "isa": isa_}))
         return
 
+    if args.exchange_probe > 0:
+        dist.init(force=True)                        # a process group of THIS rank alone: RCCL when there is a GPU, else gloo
+        print(json.dumps(dist.measure_exchange(args.exchange_probe)))
+        return
     if args.only_bf16x3:
         mean_plies, _ = load_mean_plies()
         obj = bf16x3_line(0, max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), host_cpu_share())), args.games, args.pipeline,
@@ -715,6 +741,9 @@ def main():
     per_rank_rate = dist.all_gather_floats((eng.stats["leaf_evals"] - l0) / dt_local)     # a straggler is invisible under the MAX
     rank_devices = [int(v) for v in dist.all_gather_floats(local)]                        # device ordinal of every rank
     pg = dist.group_info()
+    # the round's exchange WITH a payload (outside the timed region): what a full round of G games per rank hands over
+    exch_rows = int(round(G * mean_plies))
+    exchange = dist.measure_exchange(exch_rows, code_stride=eng.pool.code_stride, hw=H * W) if world > 1 else None
     playouts = dist.all_reduce_sum(playouts_done() - p0)
     leafs = dist.all_reduce_sum(eng.stats["leaf_evals"] - l0)
     trunk_ms = trunk_cnt = fwd_ms = fwd_cnt = 0
@@ -762,6 +791,9 @@ def main():
                                "10-block/128-filter residual net, %d concurrent games per GPU" % G,
                    "games_per_gpu": G, "leaf_batch": batch, "pipeline": args.pipeline, "host_threads": threads,
                    "mean_plies_per_game": mean_plies, "mean_plies_source": plies_src, "weights": "random init seed 0"},
+        "parity_pin": "tree / board / self-play / augmentation: pinned to the reference's own outputs (tests/golden); network: "
+                      "structure only (the reference's graph JSON) -- the 1e-4 is against this repo's float64 oracle, NOT "
+                      "against MXNet (absent); see DESIGN.md section 2",
         "ranks_seen": ranks_seen, "process_group": pg, "rank_devices": rank_devices,
         "host_threads_per_rank": threads, "host_cpu_share": ncpu,
         "per_rank_leaf_evals_per_s": per_rank_rate, "cpus_pinned_per_rank": pinned,
@@ -808,6 +840,25 @@ def main():
     if args.rehearse_on_one_gpu:
         line["valid"] = False
         line["data"] = "REHEARSAL: %d ranks share ONE GPU, collectives on gloo: plumbing of the N > 1 path with the real evaluator, NOT a scaling measurement" % world
+    if exchange is not None:
+        line["exchange"] = exchange
+    elif world == 1 and not args.plumbing_test and not args.no_extras:
+        line["exchange"] = exchange_probe_world1(exch_rows)
+    if world > 1:
+        prev = None
+        for name in ("bench_r05.json", "bench_r04.json"):
+            path = os.path.join(REPO, "profiles", name)
+            if os.path.exists(path):
+                try:
+                    with open(path) as f:
+                        cb = json.load(f).get("cpu_baseline")
+                    if cb:
+                        prev = dict(cb, source="profiles/" + name)
+                        break
+                except (ValueError, OSError):
+                    pass
+        line["cpu_baseline"] = dict(prev or {}, note="timed on rank 0 of the N = 1 run only (the host cores are busy feeding N GPUs "
+                                    "here); this is the committed N = 1 measurement, not part of this run")
     if not args.no_extras and world == 1 and not args.plumbing_test:
         line["roofline_stem"] = stem_roofline(local)
         line["latency"] = latency_probe(local)

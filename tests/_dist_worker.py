@@ -36,6 +36,13 @@ def main():
     e_codes, e_pis, e_zs = dist.all_gather_tuples(codes[:0] if rank == 0 else codes, pis[:0] if rank == 0 else pis,
                                                   zs[:0] if rank == 0 else zs)
     np.savez(os.path.join(out_dir, "gathered_empty%d.npz" % rank), codes=e_codes, pis=e_pis, zs=e_zs)
+    # the round's exchange at FULL size (BASELINE configs[3]: 1024 games x 68.4 plies per rank = 80 MB per rank), timed
+    if len(sys.argv) > 3:
+        import json
+        ex = dist.measure_exchange(int(sys.argv[3]), repeats=1)      # 15x15 rows: 240 + 900 + 4 bytes
+        if rank == 0:
+            with open(os.path.join(out_dir, "exchange.json"), "w") as f:
+                json.dump(ex, f)
     dist.barrier()
     eng.close()
 

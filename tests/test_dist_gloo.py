@@ -55,6 +55,27 @@ def test_two_rank_gloo_allgather(tmp_path):
     eng.close()
 
 
+def test_two_rank_exchange_at_full_round_size(tmp_path):
+    """The exchange with a payload: one all_gather_tuples of a whole round -- 1024 games x 68.39 plies = 70 031
+    rows x 1 144 B = 80 MB per rank -- between two gloo ranks; every rank checks every rank's rows on arrival
+    (`payload_verified`) and the figures bench.py prints are there."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = 25500 + random.randint(0, 2000)
+    rows = int(round(1024 * 68.39))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, "_dist_worker.py"),
+           str(tmp_path), "2", str(rows)]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    ex = json.load(open(tmp_path / "exchange.json"))
+    assert ex["payload_verified"] is True and ex["ranks_seen"] == 2 and ex["backend"] == "gloo"
+    assert ex["rows_per_rank"] == rows and ex["row_bytes"] == 240 + 4 * 225 + 4 and ex["bytes_sent_per_rank"] > 80e6
+    assert ex["bytes_sent_per_rank"] == rows * ex["row_bytes"] and ex["bytes_gathered_per_rank"] == 2 * rows * ex["row_bytes"]
+    assert ex["ms"] >= ex["collective_ms"] > 0 and ex["GB_per_s_collective"] > 0
+
+
 def test_bench_multi_rank_plumbing(tmp_path):
     """`torchrun ... bench.py --gpus 2` end to end on CPU ranks (gloo + stand-in evaluator):
     argument handling, rank sharding, barriers, MAX/SUM reductions, the tuple all-gather and the
@@ -77,6 +98,12 @@ def test_bench_multi_rank_plumbing(tmp_path):
     assert d["leaf_evals_per_s"] > 0 and d["value"] > 0
     assert d["config"]["games_per_gpu"] == 8
     assert d["ranks_seen"] == 2 and d["host_threads_per_rank"] >= 1 and d["launcher"] == "torchrun"
+    # the N > 1 line measures the exchange with a payload (a full round's rows per rank) and points at the CPU baseline
+    ex = d["exchange"]
+    assert ex["payload_verified"] is True and ex["ranks_seen"] == 2 and ex["backend"] == "gloo"
+    assert ex["rows_per_rank"] == int(round(8 * d["config"]["mean_plies_per_game"])) and ex["row_bytes"] == 240 + 900 + 4
+    assert ex["bytes_gathered_per_rank"] == 2 * ex["rows_per_rank"] * ex["row_bytes"] and ex["collective_ms"] > 0
+    assert "cpu_baseline" in d and "N = 1" in d["cpu_baseline"]["note"] and "parity_pin" in d
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
