@@ -26,6 +26,10 @@ e = dist.all_gather_tuples(codes[:0], pis[:0], zs[:0])
 assert e[0].shape[0] == 0
 assert dist.all_reduce_max(2.5) == 2.5 and dist.all_reduce_sum(4.0) == 4.0
 assert dist.all_gather_floats(1.5) == [1.5] and dist.broadcast_floats([1.0, 2.0]) == [1.0, 2.0]
+# the exchange at full round size (1024 games x 68.39 plies = 80 MB) through RCCL on device buffers: bench.py's `exchange`
+ex = dist.measure_exchange(int(round(1024 * 68.39)), repeats=2)
+assert ex["payload_verified"] is True and ex["backend"] == "nccl" and ex["bytes_sent_per_rank"] > 80e6 and ex["collective_ms"] > 0
+print("exchange (RCCL, world size 1):", ex["ms"], "ms whole call,", ex["collective_ms"], "ms collective")
 
 if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
     # The multi-rank training loop (alphapig_amd/pipeline.py) with the REAL trainer and evaluator, collectives on RCCL:
