@@ -203,17 +203,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
     const int cc = wave >> 2, ri = (wave >> 1) & 1, ki = wave & 1, blk = wave & 3;
     const int r31 = lane & 31, hh = lane >> 5;
     // weights: per-lane byte offsets of the two A fragments inside a unit: Fa = [hi | mid] (M1 and M3), Fb = [lo | hi] (M2)
-#ifndef APZB_V2
-#define APZB_V2 1
-#endif
-#if APZB_V2
-    // Fa = [hi | mid] (M1 and M2), Fb = [hi | lo] (M3): the lower lanes' hi is the same register content in both, so Fb's
-    // load fetches only the upper lanes' lo (lower lanes out of range: no bytes through the L1) and the lower half is
-    // copied over from Fa when the unit is used -- 1.5 KB per unit through the vector cache instead of 2
-    const unsigned a_vo0 = r31 * 16 + hh * T::VTERM, a_vo1 = hh ? r31 * 16 + 2 * T::VTERM : 0x80000000u;
-#else
     const unsigned a_vo0 = r31 * 16 + hh * T::VTERM, a_vo1 = r31 * 16 + (1 - hh) * 2 * T::VTERM;
-#endif
     const int wpos0 = 18 * ri + 3 * ki;               // first position of this wave's block
     auto pos_off = [](int p9) { return (6 * (p9 / 3) + (p9 % 3)) * T::VPOS; };   // position p9 of the block, relative to wpos0
 
@@ -297,21 +287,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
         };
         // my value and my pair partner's value of one position -> three dwords of bf16 pairs: hi = the upper halves of both
         // (truncation), remainder = value - hi (exact), ...: hi + mid + lo == value, bit for bit
-#if APZB_V2
-        // one value -> its three bf16 terms, each the UPPER half of a float: hi = trunc16(x), mid = trunc16(x - hi) (the
-        // remainder is exact), lo = trunc16(x - hi - mid): three 16-bit stores (ds_write_b16_d16_hi), two AND + two SUB;
-        // no pack instruction, no lane exchange, no select
-        auto emit1 = [&](char* vp, float x) {
-            const unsigned u = __builtin_bit_cast(unsigned, x);
-            const float r = x - __builtin_bit_cast(float, u & 0xffff0000u);
-            const unsigned ur = __builtin_bit_cast(unsigned, r);
-            const float s2 = r - __builtin_bit_cast(float, ur & 0xffff0000u);
-            *reinterpret_cast<unsigned short*>(vp) = (unsigned short)(u >> 16);
-            *reinterpret_cast<unsigned short*>(vp + T::VTERM) = (unsigned short)(ur >> 16);
-            *reinterpret_cast<unsigned short*>(vp + 2 * T::VTERM) = (unsigned short)(__builtin_bit_cast(unsigned, s2) >> 16);
-        };
-        const int tv1_off = tb * 256 + tile * 16 + chl * 2;
-#endif
         auto emit = [&](char* vp, float mine, float theirs) {
             const unsigned um = __builtin_bit_cast(unsigned, mine), ut = __builtin_bit_cast(unsigned, theirs);
             const unsigned h = __builtin_amdgcn_perm(ut, um, psel);
@@ -333,17 +308,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
             char* vp = vbase + vpar * T::V_BYTES + tv_off;
             if constexpr (K == 0) row_pass(rp, std::integral_constant<int, 0>{});
             else if constexpr (K == 1) row_pass(rp, std::integral_constant<int, 1>{});
-#if APZB_V2
-            else if constexpr (K >= 3 && K < 18) {
-                constexpr int ii = (K - 3) / 5, part = (K - 3) % 5;
-                char* v1 = vbase + vpar * T::V_BYTES + tv1_off + (3 * ph + ii) * 6 * T::VPOS;
-                if constexpr (part == 0) col_pass(tt[ii], oo);
-                else if constexpr (part == 1) { emit1(v1, oo[0]); emit1(v1 + T::VPOS, oo[1]); }
-                else if constexpr (part == 2) { emit1(v1 + 2 * T::VPOS, oo[2]); emit1(v1 + 3 * T::VPOS, oo[3]); }
-                else if constexpr (part == 3) emit1(v1 + 4 * T::VPOS, oo[4]);
-                else emit1(v1 + 5 * T::VPOS, oo[5]);
-            }
-#else
             else if constexpr (K >= 3 && K < 18) {
                 constexpr int ii = (K - 3) / 5, part = (K - 3) % 5;
                 if constexpr (part == 0) col_pass(tt[ii], oo);
@@ -360,7 +324,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
                     emit(vp + ((3 * ph + ii) * 6 + k) * T::VPOS, mine3[k], theirs3[k]);
                 }
             }
-#endif
         };
 #define APZB_ALL18(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17)
         auto transform = [&](int rpar, int vpar) {
@@ -438,41 +401,20 @@ __global__ __launch_bounds__(512) void trunk15_wino3b_kernel(const float* __rest
                 int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 asm volatile("" : "+v"(le));
                 const int b_lo0 = wpos0 * T::VPOS + (le & 31) * 16;                  // M1: B = [hi | hi]
-#if APZB_V2
-                const int b_lo1 = b_lo0 + T::VTERM;                                   // M2: B = [mid | mid]
-                const int b_lo2 = b_lo0 + (2 - 2 * (le >> 5)) * T::VTERM;             // M3: B = [lo | hi]
-                const bool upper = (le >> 5) != 0;
-#else
                 const int b_lo1 = b_lo0 + (le >> 5) * T::VTERM;                       // M2: B = [hi | mid]
                 const int b_lo2 = b_lo0 + (2 - (le >> 5)) * T::VTERM;                 // M3: B = [lo | mid]
-#endif
                 bfr[0] = *reinterpret_cast<const bf16x8*>(vp + b_lo0);
                 bfr[1] = *reinterpret_cast<const bf16x8*>(vp + b_lo1);
                 bfr[2] = *reinterpret_cast<const bf16x8*>(vp + b_lo2);
-#if APZB_V2
-                /* M3 = hi.lo + lo.hi (A = Fb with its lower half taken from Fa), M2 = hi.mid + mid.mid, M1 = hi.hi + mid.hi */
-                auto fb_of = [&](int sl) {
-                    const u32x4 lo4 = __builtin_bit_cast(u32x4, af[sl][1]), hi4 = __builtin_bit_cast(u32x4, af[sl][0]);
-                    u32x4 r;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) r[i] = upper ? lo4[i] : hi4[i];
-                    return __builtin_bit_cast(bf16x8, r);
-                };
-#define APZB_A3(sl) fb_of(sl)
-#define APZB_A2(sl) af[sl][0]
-#else
-#define APZB_A3(sl) af[sl][0]
-#define APZB_A2(sl) af[sl][1]
-#endif
 #define APZB_SLOT(k)                                                                                                     \
                 {                                                                                                        \
                     constexpr int p9 = (k), slot = (par * 9 + (k)) % RING;                                               \
-                    /* smallest products first (V1: M3 = hi.lo + mid.mid, M2 = lo.hi + hi.mid, M1 = hi.hi + mid.hi) */   \
+                    /* smallest products first: M3 = hi.lo + mid.mid, M2 = lo.hi + hi.mid, M1 = hi.hi + mid.hi */        \
                     /* every V fragment is re-read for the next position right behind the one MFMA that uses it: the      \
                        fragment the next slot needs first (M3's) is requested two MFMA times ahead */                      \
-                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(APZB_A3(slot), bfr[2], acc[p9], 0, 0, 0);          \
+                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][0], bfr[2], acc[p9], 0, 0, 0);            \
                     if (p9 + 1 < 9 && !APZB_ABL_B) bfr[2] = *reinterpret_cast<const bf16x8*>(vp + b_lo2 + pos_off(p9 + 1)); \
-                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(APZB_A2(slot), bfr[1], acc[p9], 0, 0, 0);          \
+                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][1], bfr[1], acc[p9], 0, 0, 0);            \
                     if (p9 + 1 < 9 && !APZB_ABL_B) bfr[1] = *reinterpret_cast<const bf16x8*>(vp + b_lo1 + pos_off(p9 + 1)); \
                     acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][0], bfr[0], acc[p9], 0, 0, 0);            \
                     if (p9 + 1 < 9 && !APZB_ABL_B) bfr[0] = *reinterpret_cast<const bf16x8*>(vp + b_lo0 + pos_off(p9 + 1)); \

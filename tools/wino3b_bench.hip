@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "trunk15_wino3c.h"
+#include "trunk15_wino3b.h"
 
 // Y = A^T [sum_ci U (.) B^T d B] A + bias (+ resid), ReLU -- the definition, in double.  upk: wino_common.h's fp32 layout.
 __global__ void wino_ref_kernel(const float* __restrict__ in, const float* __restrict__ upk, const float* __restrict__ bias,
@@ -68,9 +68,6 @@ int main(int argc, char** argv) {
     using T2 = apz::WinoPack;
     using T3 = apz::Wino3;
     using TB = apz::Wino3B;
-    using TC = apz::Wino3C;
-    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TC::LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TC::LDS_BYTES));
     const bool quick = getenv("APZ_NO_TIMING") != nullptr;
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T3::LDS_BYTES));
@@ -78,12 +75,10 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)apz::trunk15_wino3b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TB::LDS_BYTES));
     const int nmax = 2048;
     const size_t act = (size_t)nmax * 128 * 240;
-    float *in, *res, *out, *out2, *out3, *upk, *bias, *scr;
+    float *in, *res, *out, *out2, *upk, *bias;
     double* outd;
     void* upkb;
     CK(hipMalloc(&in, act * 4)); CK(hipMalloc(&res, act * 4)); CK(hipMalloc(&out, act * 4)); CK(hipMalloc(&out2, act * 4));
-    CK(hipMalloc(&out3, act * 4));
-    CK(hipMalloc(&scr, (size_t)256 * TC::SCRATCH_FLOATS_PER_WG * 4));
     const int nref = 1030;
     CK(hipMalloc(&outd, (size_t)nref * 128 * 240 * 8));
     CK(hipMalloc(&upk, T2::UPK_FLOATS * 4)); CK(hipMalloc(&bias, 128 * 4)); CK(hipMalloc(&upkb, TB::UPK_BYTES));
@@ -117,8 +112,6 @@ int main(int argc, char** argv) {
         for (int it = 0; it < 12; it++) {
             hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512);
             hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(256), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, 512);
-            hipLaunchKernelGGL((apz::trunk15_wino3c_kernel<true>), dim3(256), dim3(512), TC::LDS_BYTES, 0, in, upkb, bias, res, out3, scr, 512);
-            hipLaunchKernelGGL((apz::trunk15_wino3c_kernel<false>), dim3(256), dim3(512), TC::LDS_BYTES, 0, in, upkb, bias, res, out3, scr, 512);
             hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(256), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, 512);
             hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(256), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, 512);
         }
@@ -129,7 +122,7 @@ int main(int argc, char** argv) {
     // ---- cross-check against the naive double kernel at ragged sizes
     int bad = 0;
     const int check_sizes[7] = {1, 7, 64, 96, 512, 515, 1030};
-    std::vector<float> ha, hb3, hc;
+    std::vector<float> ha, hb3;
     std::vector<double> hd;
     for (int ci = 0; ci < (quick ? 3 : 7); ci++) {
         const int n = check_sizes[ci];
@@ -138,10 +131,6 @@ int main(int argc, char** argv) {
             const size_t cnt = (size_t)n * 128 * 240;
             CK(hipMemset(out, 0xff, cnt * 4));
             CK(hipMemset(out2, 0xff, cnt * 4));
-            CK(hipMemset(out3, 0xff, cnt * 4));
-            const int gridc = apz::wino3c_grid(n, 256);
-            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3c_kernel<true>), dim3(gridc), dim3(512), TC::LDS_BYTES, 0, in, upkb, bias, res, out3, scr, n);
-            else hipLaunchKernelGGL((apz::trunk15_wino3c_kernel<false>), dim3(gridc), dim3(512), TC::LDS_BYTES, 0, in, upkb, bias, res, out3, scr, n);
             hipLaunchKernelGGL(wino_ref_kernel, dim3((unsigned)((n * 128 * 16 + 255) / 256)), dim3(256), 0, 0, in, upk, bias, res, outd, n, resid);
             if (resid) {
                 hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n);
@@ -152,28 +141,22 @@ int main(int argc, char** argv) {
             }
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
-            ha.resize(cnt); hb3.resize(cnt); hd.resize(cnt); hc.resize(cnt);
-            CK(hipMemcpy(hc.data(), out3, cnt * 4, hipMemcpyDeviceToHost));
+            ha.resize(cnt); hb3.resize(cnt); hd.resize(cnt);
             CK(hipMemcpy(ha.data(), out, cnt * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(hb3.data(), out2, cnt * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(hd.data(), outd, cnt * 8, hipMemcpyDeviceToHost));
-            double eb = 0, e3 = 0, scale = 0, sb = 0, s3 = 0, ec = 0, sc2 = 0;
-            size_t worst = 0, nonfinite = 0, worstc = 0;
+            double eb = 0, e3 = 0, scale = 0, sb = 0, s3 = 0;
+            size_t worst = 0, nonfinite = 0;
             for (size_t i = 0; i < cnt; i++) {
                 if ((i % 240) / 16 >= 15) continue;
-                if (!std::isfinite(ha[i]) || !std::isfinite(hc[i])) { nonfinite++; if (!std::isfinite(hc[i])) worstc = i; continue; }
-                const double dc = std::fabs((double)hc[i] - hd[i]);
-                if (dc > ec) { ec = dc; worstc = i; }
-                sc2 += dc * dc;
+                if (!std::isfinite(ha[i])) { nonfinite++; continue; }
                 const double db = std::fabs((double)ha[i] - hd[i]), d3 = std::fabs((double)hb3[i] - hd[i]);
                 if (db > eb) { eb = db; worst = i; }
                 e3 = std::max(e3, d3);
                 sb += db * db; s3 += d3 * d3;
                 scale = std::max(scale, std::fabs(hd[i]));
             }
-            const bool ok = nonfinite == 0 && eb < 2e-5 * std::max(1.0, scale) && ec < 2e-5 * std::max(1.0, scale);
-            printf("check n=%5d resid=%d grid=%d: two-pass bf16x3 max err %.3e rms %.3e (worst at board %zu ch %zu row %zu col %zu: %.6f vs %.6f)\n", n, resid,
-                   gridc, ec, std::sqrt(sc2 / cnt), worstc / (128 * 240), (worstc / 240) % 128, (worstc % 240) / 16, worstc % 16, hc[worstc], hd[worstc]);
+            const bool ok = nonfinite == 0 && eb < 2e-5 * std::max(1.0, scale);
             if (!ok) bad++;
             printf("check n=%5d resid=%d grid=%d: bf16x3 max err %.3e rms %.3e | fp32 wino3 max err %.3e rms %.3e | scale %.2f nonfinite %zu %s (worst at board %zu ch %zu row %zu col %zu: %.6f vs %.6f)\n",
                    n, resid, grid, eb, std::sqrt(sb / cnt), e3, std::sqrt(s3 / cnt), scale, nonfinite, ok ? "OK" : "MISMATCH", worst / (128 * 240),
@@ -190,20 +173,16 @@ int main(int argc, char** argv) {
     for (int si = 0; si < 5; si++) {
         const int n = sizes[si];
         const int grid = apz::wino3_grid(n, 256);
-        float best[3][2] = {{1e9f, 1e9f}, {1e9f, 1e9f}, {1e9f, 1e9f}}, sum[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-        const int gridc = apz::wino3c_grid(n, 256);
+        float best[2][2] = {{1e9f, 1e9f}, {1e9f, 1e9f}}, sum[2][2] = {{0, 0}, {0, 0}};
         const int rounds = 6, iters = 20;
         for (int r = 0; r < rounds; r++)
-            for (int kern = 0; kern < 3; kern++)
+            for (int kern = 0; kern < 2; kern++)
                 for (int resid = 0; resid < 2; resid++) {
                     for (int it = -3; it < iters; it++) {
                         if (it == 0) CK(hipEventRecord(e0, 0));
                         if (kern == 0) {
                             if (resid) hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<true>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n);
                             else hipLaunchKernelGGL((apz::trunk15_wino3b_kernel<false>), dim3(grid), dim3(512), TB::LDS_BYTES, 0, in, upkb, bias, res, out, n);
-                        } else if (kern == 2) {
-                            if (resid) hipLaunchKernelGGL((apz::trunk15_wino3c_kernel<true>), dim3(gridc), dim3(512), TC::LDS_BYTES, 0, in, upkb, bias, res, out3, scr, n);
-                            else hipLaunchKernelGGL((apz::trunk15_wino3c_kernel<false>), dim3(gridc), dim3(512), TC::LDS_BYTES, 0, in, upkb, bias, res, out3, scr, n);
                         } else {
                             if (resid) hipLaunchKernelGGL((apz::trunk15_wino3_kernel<true>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
                             else hipLaunchKernelGGL((apz::trunk15_wino3_kernel<false>), dim3(grid), dim3(512), T3::LDS_BYTES, 0, in, upk, bias, res, out2, n);
@@ -216,30 +195,10 @@ int main(int argc, char** argv) {
                     best[kern][resid] = std::min(best[kern][resid], ms / iters);
                     sum[kern][resid] += ms / iters;
                 }
-        printf("time n=%5d grid=%3d: bf16x3 %.1f / %.1f us (plain / resid; mean %.1f / %.1f) | two-pass bf16x3 %.1f / %.1f us (mean %.1f / %.1f) | fp32 wino3 %.1f / %.1f us (mean %.1f / %.1f)\n", n, grid,
-               best[0][0] * 1e3, best[0][1] * 1e3, sum[0][0] / rounds * 1e3, sum[0][1] / rounds * 1e3, best[2][0] * 1e3, best[2][1] * 1e3,
-               sum[2][0] / rounds * 1e3, sum[2][1] / rounds * 1e3, best[1][0] * 1e3, best[1][1] * 1e3,
+        printf("time n=%5d grid=%3d: bf16x3 %.1f / %.1f us (plain / resid; mean %.1f / %.1f) | fp32 wino3 %.1f / %.1f us (mean %.1f / %.1f)\n", n, grid,
+               best[0][0] * 1e3, best[0][1] * 1e3, sum[0][0] / rounds * 1e3, sum[0][1] / rounds * 1e3, best[1][0] * 1e3, best[1][1] * 1e3,
                sum[1][0] / rounds * 1e3, sum[1][1] / rounds * 1e3);
-        fflush(stdout);
     }
-#ifdef APZ_WINO3C_STAMPS
-    {
-        unsigned long long st[4 * 8 * 8];
-        hipLaunchKernelGGL((apz::trunk15_wino3c_kernel<true>), dim3(256), dim3(512), TC::LDS_BYTES, 0, in, upkb, bias, res, out3, scr, 512);
-        CK(hipDeviceSynchronize());
-        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(apz::apz_wino3c_stamps), sizeof st));
-        unsigned tr[8 * 128];
-        CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(apz::apz_wino3c_trace), sizeof tr));
-        for (int ev = 0; ev < 128; ev++) {
-            printf("trace ev %3d ph %u:", ev, tr[ev] >> 28);
-            for (int w = 0; w < 8; w++) printf(" %6u", tr[w * 128 + ev] & 0x0fffffffu);
-            printf("\n");
-        }
-        for (int w = 0; w < 8; w++)
-            printf("two-pass stamps wg0 wave %d: prologue %llu barriers %llu chunks %llu epilogue %llu total %llu cycles\n", w, st[w * 8 + 0], st[w * 8 + 1],
-                   st[w * 8 + 2], st[w * 8 + 3], st[w * 8 + 7]);
-    }
-#endif
 #ifdef APZ_WINO3B_STAMPS
     {
         unsigned long long st[4 * 8 * 8];
