@@ -1,7 +1,7 @@
 // Trunk 3x3 convolution (128 -> 128 channels, 15x15 board) + folded BN + (residual) + ReLU as a
 // fused F(4x4,3x3) Winograd convolution on the fp32 matrix cores -- SINGLE PASS: a work item is
 // two boards x 64 output channels with all 36 transformed positions.  gfx950 only.
-// Successor of round 1's two-pass kernel (same math, same HBM layouts, same packed weights; git history / DESIGN section 4).
+// Successor of round 1's two-pass kernel (same math, same HBM layouts, same packed weights; git history / HISTORY.md section 4).
 //
 // Why (measurements of that kernel, profiles/r01_trunk_winograd.md): two boards x 128
 // channels x 36 positions of accumulators (590 KB) do not fit the 512 KB register file, so round 1 made

@@ -5,7 +5,7 @@
 // below 2^-24 of the product; fp32 rounds every product to 2^-24.  gfx950 only.  Opt-in (apz_set_trunk_arith): the
 // default trunk kernel stays trunk15_wino3.h's exact-fp32 one, whose bits the parity tests rest on.
 //
-// Why this shape.  v_mfma_f32_32x32x16_bf16 does 16x the flops of v_mfma_f32_16x16x4_f32
+// Why this shape (HISTORY.md section 9, round 4; round 5: profiles/r05_wino3b.md).  v_mfma_f32_32x32x16_bf16 does 16x the flops of v_mfma_f32_16x16x4_f32
 // per cycle, so six products per fp32 product leave 2.7x -- but operands now have to arrive 8x faster per MFMA cycle:
 //   * K packing.  One MFMA contracts k = 16.  A chunk is 8 input channels; the two k halves (lanes 0-31 / 32-63 hold
 //     k = 0-7 / 8-15) carry two DIFFERENT term pairings of the same 8 channels:

@@ -337,3 +337,68 @@ class PolicyValueNet(object):
 
     def sync(self):
         self._ck(self.L.apz_sync(self._h))
+
+
+class LanedEvaluator(object):
+    """k PolicyValueNet handles holding the same weights behind ONE slot interface: slot s runs on lane s % k.  Every lane
+    is a C-ABI engine of its own -- its own HIP stream, its own activation buffers -- so the forwards of SelfPlayEngine's
+    pipeline groups OVERLAP on the GPU instead of queueing on one stream.  For nets whose per-group launches leave most
+    of the chip idle and are bound by launch gaps and round trips: BASELINE configs[1] (8x8 simple net, 32-board
+    forwards of seven launches each: policy_value_net_mxnet_simple.py:68-92).  The 15x15 / 1024-game configuration
+    fills the chip with every launch and keeps one lane (kernels that never overlap: clean per-kernel timings).
+    A position's outputs do not depend on the lane: same kernels, same weights, same bits."""
+
+    def __init__(self, lanes):
+        if not lanes:
+            raise ValueError("at least one lane")
+        self.lanes = list(lanes)
+        first = self.lanes[0]
+        self.n_slots = max(first.n_slots, len(self.lanes))
+        self.batchsize, self.hw, self.code_stride = first.batchsize, first.hw, first.code_stride
+        for ln in self.lanes[1:]:
+            if (ln.batchsize, ln.hw, ln.code_stride) != (self.batchsize, self.hw, self.code_stride):
+                raise ValueError("lanes must be evaluators of the same shape")
+
+    @classmethod
+    def like(cls, net, n_lanes, **kw):
+        """`net` plus n_lanes - 1 more PolicyValueNet handles built from its parameters."""
+        extra = [PolicyValueNet(net.board_width, net.board_height, net.batchsize, n_blocks=net._n_blocks,
+                                n_filter=net._n_filter, model_params=net.params(), net_kind=net.net_kind, c_in=net.channelnum, device=net._device,
+                                trunk_arith=net.trunk_arith, **kw) for _ in range(int(n_lanes) - 1)]
+        return cls([net] + extra)
+
+    def _lane(self, slot):
+        return self.lanes[int(slot) % len(self.lanes)], int(slot) // len(self.lanes)
+
+    def evaluate_codes(self, codes):
+        return self.lanes[0].evaluate_codes(codes)
+
+    def evaluate_codes_slot(self, slot, codes):
+        ln, s = self._lane(slot)
+        return ln.evaluate_codes_slot(s, codes)
+
+    def submit_codes_slot(self, slot, codes):
+        ln, s = self._lane(slot)
+        return ln.submit_codes_slot(s, codes)
+
+    def wait_slot(self, slot, n):
+        ln, s = self._lane(slot)
+        return ln.wait_slot(s, n)
+
+    def sample_moves(self, *a, **kw):
+        return self.lanes[0].sample_moves(*a, **kw)
+
+    def set_params(self, model_params, **kw):
+        for ln in self.lanes:
+            ln.set_params(model_params, **kw)
+
+    def params(self):
+        return self.lanes[0].params()
+
+    def sync(self):
+        for ln in self.lanes:
+            ln.sync()
+
+    def close(self):
+        for ln in self.lanes:
+            ln.close()

@@ -58,13 +58,16 @@ def config1(n_games=4):
     return out
 
 
-def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None):
-    from alphapig_amd.policy_value_net import PolicyValueNet
+def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None, lanes=1, pipeline=2):
+    """lanes > 1: one evaluator handle (own HIP stream, own buffers) per pipeline group -- policy_value_net.LanedEvaluator."""
+    from alphapig_amd.policy_value_net import LanedEvaluator, PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
     prm = weights.init_params(kind, w, w, 9, n_blocks, 128, seed=0, style="bench")
-    net = PolicyValueNet(w, w, batch_size=max(16, G // 2), n_blocks=n_blocks, n_filter=128, model_params=prm,
+    net = PolicyValueNet(w, w, batch_size=max(16, G // pipeline), n_blocks=n_blocks, n_filter=128, model_params=prm,
                          net_kind=kind)
-    eng = SelfPlayEngine(net, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=77, pipeline=2,
+    if lanes > 1:
+        net = LanedEvaluator.like(net, lanes)
+    eng = SelfPlayEngine(net, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=77, pipeline=pipeline,
                          forced_opening=(w == 15), temp_schedule=temp_schedule)
     info0 = eng.pool.pool_info()
     eng.run_steps(30)
@@ -78,7 +81,7 @@ def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None):
            "moves_per_s": (eng.stats["moves"] - m0) / dt, "games_finished": eng.stats["games"] - g0,
            "ms_per_step": 1e3 * dt / steps, "host_tree_s": eng.timers["host_s"], "evaluator_s": eng.timers["eval_s"],
            "tree_arena_gb": info0["arena_bytes"] / 1e9, "tree_arena_pretouched": info0["pretouched"],
-           "peak_tree_nodes": eng.pool.pool_info()["peak_nodes"]}
+           "peak_tree_nodes": eng.pool.pool_info()["peak_nodes"], "evaluator_lanes": lanes, "pipeline_groups": pipeline}
     if eng.stats["games"] - g0 > 0:
         res["mean_plies_finished"] = (eng.stats["plies"] - p0) / (eng.stats["games"] - g0)
         res["games_per_s_finished"] = (eng.stats["games"] - g0) / dt

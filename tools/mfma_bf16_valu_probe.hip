@@ -1,4 +1,4 @@
-// Probe for the next design step ("fp32-accurate split on the bf16 matrix pipe"): does VALU work
+// Probe for the next design step (HISTORY.md section 9, "fp32-accurate split on the bf16 matrix pipe"): does VALU work
 // hide in the shadow of v_mfma_f32_16x16x32_bf16 on gfx950 (it does NOT under v_mfma_f32_16x16x4_f32:
 // tools/mfma_valu_probe.hip), and what does one such MFMA cost per wave with 1 / 2 waves per SIMD?
 // Loop of 16 MFMAs (independent accumulators) with K `v_fma_f32` after each.
