@@ -131,7 +131,7 @@ def cpu_baseline(mean_plies, cores, budget_s=15.0):
                       % (total_n, len(rates), isa, budget_s)}
 
 
-def exchange_probe_world1(rows, timeout_s=180.0):
+def exchange_probe_world1(rows, timeout_s=75.0):
     """The N = 1 line's `exchange`: the same dist.measure_exchange as the N > 1 line runs inline, in a child process that
     forms a process group of one rank (RCCL on the GPU box) -- a child so that a backend that fails to come up costs
     this object, not the line."""
@@ -142,12 +142,25 @@ def exchange_probe_world1(rows, timeout_s=180.0):
         port = sk.getsockname()[1]
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port))
+    # Bounded whatever the child does: its own session, killed as a group at the deadline, and ABANDONED if it does not
+    # die (a child stuck inside the driver cannot be waited for) -- the line is worth more than this object
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--exchange-probe", str(int(rows))], env=env, cwd=REPO,
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-probe", str(int(rows))], env=env, cwd=REPO,
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-        obj = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        out, _ = p.communicate(timeout=timeout_s)
+        obj = json.loads(out.decode().strip().splitlines()[-1])
         obj["process"] = "child process, process group of one rank"
         return obj
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, 9)
+        except OSError:
+            pass
+        try:
+            p.communicate(timeout=5)
+        except Exception:      # noqa: BLE001
+            pass
+        return {"error": "the one-rank process group did not answer within %.0f s (child killed or abandoned)" % timeout_s}
     except Exception as e:            # noqa: BLE001 -- reported on the line
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
@@ -845,8 +858,6 @@ def main():
         line["data"] = "REHEARSAL: %d ranks share ONE GPU, collectives on gloo: plumbing of the N > 1 path with the real evaluator, NOT a scaling measurement" % world
     if exchange is not None:
         line["exchange"] = exchange
-    elif world == 1 and not args.plumbing_test and not args.no_extras:
-        line["exchange"] = exchange_probe_world1(exch_rows)
     if world > 1:
         prev = None
         for name in ("bench_r05.json", "bench_r04.json"):
@@ -863,12 +874,15 @@ def main():
         line["cpu_baseline"] = dict(prev or {}, note="timed on rank 0 of the N = 1 run only (the host cores are busy feeding N GPUs "
                                     "here); this is the committed N = 1 measurement, not part of this run")
     if not args.no_extras and world == 1 and not args.plumbing_test:
-        line["roofline_stem"] = stem_roofline(local)
-        line["latency"] = latency_probe(local)
-        line["trunk_bf16x3"] = bf16x3_line(local, threads, G, args.pipeline, mean_plies)
-        line["train_step"] = train_step_line(local)
-        line["config2"] = config2_line(local)
-        line["cpu_baseline"] = cpu_baseline(mean_plies, cores=max(1, min(16, ncpu)))
+        for key, fn in (("roofline_stem", lambda: stem_roofline(local)), ("latency", lambda: latency_probe(local)),
+                        ("trunk_bf16x3", lambda: bf16x3_line(local, threads, G, args.pipeline, mean_plies)),
+                        ("train_step", lambda: train_step_line(local)), ("config2", lambda: config2_line(local)),
+                        ("cpu_baseline", lambda: cpu_baseline(mean_plies, cores=max(1, min(16, ncpu))))):
+            heartbeat("extra: %s" % key)
+            line[key] = fn()
+        heartbeat("extra: exchange probe (child process, one-rank process group)")
+        line["exchange"] = exchange_probe_world1(exch_rows)     # last: bounded, and nothing else depends on it
+        heartbeat("extras done")
     print(json.dumps(line))
 
 

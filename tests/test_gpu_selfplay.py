@@ -449,3 +449,28 @@ def test_config5_slice_1024_games_n_playout_1600():
     assert eng.pool.pool_info()["peak_nodes"] <= cap
     eng.close()
     net.close()
+
+
+def test_laned_evaluator_overlapping_streams_play_the_same_games():
+    """policy_value_net.LanedEvaluator: one engine handle (own HIP stream, own activation buffers) per pipeline group, so
+    the groups' forwards overlap on the GPU (BASELINE configs[1]: 8x8, simple net, policy_value_net_mxnet_simple.py:68-92).
+    A position's outputs do not depend on the lane, so the games are the single-lane engine's games, bit for bit."""
+    from alphapig_amd.policy_value_net import LanedEvaluator, PolicyValueNet
+    prm = weights.init_params("simple", 8, 8, 9, seed=1, style="bench")
+    out = []
+    for lanes, pipeline in ((1, 2), (2, 2), (2, 4)):
+        net = PolicyValueNet(8, 8, batch_size=32, model_params=prm, net_kind="simple")
+        ev = LanedEvaluator.like(net, lanes) if lanes > 1 else net
+        eng = SelfPlayEngine(ev, 8, 8, 4, n_games=16, n_playout=40, temp=1.0, base_seed=4242, n_threads=2, pipeline=pipeline,
+                             forced_opening=False)
+        eps = eng.play_games(12)
+        out.append(eps)
+        eng.close()
+        ev.close()
+    for other in out[1:]:
+        assert [e.index for e in other] == [e.index for e in out[0]]
+        for a, b in zip(out[0], other):
+            np.testing.assert_array_equal(a.moves, b.moves)
+            np.testing.assert_array_equal(a.pis, b.pis)
+            np.testing.assert_array_equal(a.zs, b.zs)
+            assert a.winner == b.winner
