@@ -47,7 +47,7 @@ N_PLAYOUT = 400
 N_BLOCKS = 10
 N_FILTER = 128
 GAMES_PER_GPU = 1024
-CALIB = os.path.join(REPO, "profiles", "calibration_r04.json")
+CALIB = os.path.join(REPO, "profiles", "calibration_r05.json")
 FP32_MATRIX_PEAK_TF = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA peak
 BF16_MATRIX_PEAK_TF = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
 HBM_PEAK_GBS = 8000.0
@@ -61,7 +61,7 @@ def load_mean_plies():
     if os.path.exists(CALIB):
         with open(CALIB) as f:
             c = json.load(f)
-        return float(c["mean_plies_per_game"]), "profiles/calibration_r04.json (%d complete games counted in steady state, MI355X)" % c["games"]
+        return float(c["mean_plies_per_game"]), "profiles/calibration_r05.json (%d complete games counted in steady state, MI355X)" % c["games"]
     return None, None
 
 
@@ -181,7 +181,7 @@ def stem_roofline(device):
         ms = net.conv_bench(0, n, iters=50, warmup=10)
         alg = n * (c_in * H * W + N_FILTER * H * W) * 4 + N_FILTER * c_in * 9 * 4
         traffic = None
-        tpath = os.path.join(REPO, "profiles", "r02_stem_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r05_stem_traffic.json")
         if os.path.exists(tpath):                      # PMC passes of rocprofv3 on tools/stem_profile.py (same launches)
             with open(tpath) as f:
                 traffic = json.load(f).get("c_in_%d" % c_in, {}).get("traffic_bytes_per_launch")
@@ -287,22 +287,26 @@ def train_step_line(device, steps=10, warmup=3):
 def config2_line(device, steps=4000, warmup=50):
     """BASELINE configs[1] (the metric's CPU-runnable sibling: 64 concurrent 8x8 games, 4 in a row, n_playout 200, the 6-conv
     net) through the same engine: leaf evaluations per second.  An EXTRA object (tests/config_table.py is the same measurement)."""
-    from alphapig_amd.policy_value_net import PolicyValueNet
+    from alphapig_amd.policy_value_net import LanedEvaluator, PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
     prm = weights.init_params("simple", 8, 8, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
     net = PolicyValueNet(8, 8, batch_size=32, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, net_kind="simple", device=device)
-    eng = SelfPlayEngine(net, 8, 8, 4, n_games=64, n_playout=200, temp=1.0, base_seed=77, pipeline=2, forced_opening=False)
+    # one engine handle (own HIP stream) per pipeline group: the two groups' seven-launch forwards overlap on the GPU
+    # (round 5: 337-353 k -> 402-415 k leaf evaluations per second, profiles/r05_config2.md); same games, bit for bit
+    ev = LanedEvaluator.like(net, 2)
+    eng = SelfPlayEngine(ev, 8, 8, 4, n_games=64, n_playout=200, temp=1.0, base_seed=77, pipeline=2, forced_opening=False)
     eng.run_steps(warmup)
-    net.sync()
+    ev.sync()
     l0 = eng.stats["leaf_evals"]
     t = time.perf_counter()
     eng.run_steps(steps)
-    net.sync()
+    ev.sync()
     dt = time.perf_counter() - t
     leafs = eng.stats["leaf_evals"] - l0
     eng.close()
-    net.close()
-    return {"workload": "64 concurrent 8x8 games, n_in_row 4, n_playout 200, simple 6-conv net, 32-board forwards", "steps": steps,
+    ev.close()
+    return {"workload": "64 concurrent 8x8 games, n_in_row 4, n_playout 200, simple 6-conv net, 32-board forwards, one evaluator lane "
+                        "(HIP stream) per pipeline group", "steps": steps, "evaluator_lanes": 2,
             "leaf_evals_per_s": leafs / dt, "ms_per_step": 1e3 * dt / steps}
 
 
@@ -687,7 +691,7 @@ def main():
             ln.close()
         return
     if mean_plies is None:
-        raise SystemExit("profiles/calibration_r04.json missing: run `python bench.py --count-games 240` once")
+        raise SystemExit("profiles/calibration_r05.json missing: run `python bench.py --count-games 240` once")
 
     import gc
     gc.collect()
@@ -781,7 +785,7 @@ def main():
     # HBM / fabric traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
     # (cannot be collected from inside the process), committed under profiles/
     traffic, traffic_src = None, None
-    for tname in ("r04_trunk_traffic.json", "r03_trunk_traffic.json", "r02_trunk_traffic.json"):
+    for tname in ("r05_trunk_traffic.json", "r04_trunk_traffic.json", "r03_trunk_traffic.json", "r02_trunk_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if os.path.exists(tpath):
             with open(tpath) as f:

@@ -122,7 +122,8 @@ def config2_roofline(n=32):
 
 def main():
     out = {"config1_pure_mcts_8x8_n100_cpu": config1()}
-    out["config2_simple_net_8x8_n200_64games"] = gpu_config("simple", 8, 4, 200, 64, 6000)
+    out["config2_simple_net_8x8_n200_64games"] = gpu_config("simple", 8, 4, 200, 64, 6000, lanes=2)
+    out["config2_simple_net_8x8_n200_64games_one_lane"] = gpu_config("simple", 8, 4, 200, 64, 6000, lanes=1)
     out["config2_simple_net_8x8_n200_64games"]["kernels"] = config2_roofline(32)
     out["config3_resnet10_15x15_n400_1024games"] = gpu_config("resnet", 15, 5, 400, 1024, 400)
     out["config5_slice_resnet10_15x15_n1600_1024games"] = gpu_config("resnet", 15, 5, 1600, 1024, 2000,
