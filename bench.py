@@ -310,6 +310,32 @@ def config2_line(device, steps=4000, warmup=50):
             "leaf_evals_per_s": leafs / dt, "ms_per_step": 1e3 * dt / steps}
 
 
+def config2_child(timeout_s=120.0):
+    """config2_line in a FRESH process: inside the bench process, after the other extras have created and destroyed half a
+    dozen engines, the two lanes' streams no longer overlap (353 k instead of 385 - 415 k leaf evaluations/s, measured); a
+    process that creates just these two streams gets two hardware queues.  Bounded like the exchange probe."""
+    import subprocess
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--config2-worker"], cwd=REPO, stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+        obj = json.loads(out.decode().strip().splitlines()[-1])
+        obj["process"] = "child process (fresh HIP context)"
+        return obj
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, 9)
+        except OSError:
+            pass
+        try:
+            p.communicate(timeout=5)
+        except Exception:      # noqa: BLE001
+            pass
+        return {"error": "no answer within %.0f s" % timeout_s}
+    except Exception as e:            # noqa: BLE001 -- reported on the line
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
 def _rank_log_dir(tag=None):
     """gpurun_out/ (travels back from the GPU box), one sub-directory per self-spawned job: two bench runs on one host
     must not truncate each other's rank logs, and the supervisor's silence watchdog sums the sizes of its OWN ranks' logs.
@@ -515,6 +541,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem, latency, trunk_bf16x3, train_step, config2 and cpu_baseline")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # child of cpu_baseline()
     ap.add_argument("--exchange-probe", type=int, default=0, metavar="ROWS", help=argparse.SUPPRESS)   # child of exchange_probe_world1()
+    ap.add_argument("--config2-worker", action="store_true", help=argparse.SUPPRESS)                   # child of config2_child()
     ap.add_argument("--profile-every", type=int, default=16, help="HIP-event-time every k-th forward in the timed region")
     ap.add_argument("--profile-samples", type=int, default=20, help="... or more often, for at least this many timed forwards")
     ap.add_argument("--mean-plies", type=float, default=None, help="debug override of the calibrated mean plies/game")
@@ -542,6 +569,9 @@ def main():
         print(json.dumps({"n": n_, "dt": dt_, "isa": isa_}))
         return
 
+    if args.config2_worker:
+        print(json.dumps(config2_line(0)))
+        return
     if args.exchange_probe > 0:
         dist.init(force=True)                        # a process group of THIS rank alone: RCCL when there is a GPU, else gloo
         print(json.dumps(dist.measure_exchange(args.exchange_probe)))
@@ -880,7 +910,7 @@ def main():
     if not args.no_extras and world == 1 and not args.plumbing_test:
         for key, fn in (("roofline_stem", lambda: stem_roofline(local)), ("latency", lambda: latency_probe(local)),
                         ("trunk_bf16x3", lambda: bf16x3_line(local, threads, G, args.pipeline, mean_plies)),
-                        ("train_step", lambda: train_step_line(local)), ("config2", lambda: config2_line(local)),
+                        ("train_step", lambda: train_step_line(local)), ("config2", lambda: config2_child()),
                         ("cpu_baseline", lambda: cpu_baseline(mean_plies, cores=max(1, min(16, ncpu))))):
             heartbeat("extra: %s" % key)
             line[key] = fn()
