@@ -161,13 +161,14 @@ def test_full_configuration_engine_equals_sequential_oracle(arith):
     net.close()
 
 
-def test_full_size_properties_1024_games():
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_full_size_properties_1024_games(arith):
     """BASELINE config 3 at full width (1024 concurrent games, 10 blocks, n_playout=400) for a few
-    rounds: size-independent properties -- one leaf per active game per round, priors are a
-    distribution, visit counts add up, Q in [-1, 1]."""
+    rounds, on both trunk arithmetics: size-independent properties -- one leaf per active game per round,
+    priors are a distribution, visit counts add up, Q in [-1, 1]."""
     from alphapig_amd.policy_value_net import PolicyValueNet
     prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
-    net = PolicyValueNet(15, 15, batch_size=1024, n_blocks=10, n_filter=128, model_params=prm)
+    net = PolicyValueNet(15, 15, batch_size=1024, n_blocks=10, n_filter=128, model_params=prm, trunk_arith=arith)
     eng = SelfPlayEngine(net, 15, 15, 5, n_games=1024, n_playout=400, temp=1.0, base_seed=1, pipeline=2)
     rounds = 12
     n = eng.run_steps(rounds)
