@@ -33,10 +33,12 @@ def init(backend=None, device_index=None, force=False):
         if backend == "nccl":
             torch.cuda.set_device(local if device_index is None else device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # Ranks legitimately sit in a collective for a long time while rank 0 runs an arena evaluation or an SGF phase
-        # (pipeline.py); the backend default (10 minutes on NCCL / RCCL) would let the watchdog kill such a job.
+        # Ranks legitimately sit in a collective while rank 0 runs an arena evaluation (lock-step schedule) or drains its
+        # trainer thread at the end of a run (asynchronous schedule: pipeline.py); the backend default (10 minutes on
+        # NCCL / RCCL) can be too short for that, two hours left the GPUs of a job whose rank 0 had crashed hanging for
+        # two hours.  30 minutes; a trainer that dies is announced in the round header, not by a timeout.
         import datetime
-        timeout = datetime.timedelta(seconds=float(os.environ.get("APZ_DIST_TIMEOUT_S", "7200")))
+        timeout = datetime.timedelta(seconds=float(os.environ.get("APZ_DIST_TIMEOUT_S", "1800")))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
