@@ -2,6 +2,7 @@
 # Round-5 measurement batch (run ON THE GPU BOX via gpurun from the repo root); everything lands in gpurun_out/r05p/.
 #   tools/r05_measure.sh [quick]     quick: no count-games window
 set -o pipefail
+MODE=${1:-full}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/r05p
 mkdir -p $OUT
@@ -30,7 +31,7 @@ echo "== config table" | tee -a $OUT/log.txt
 python3 tests/config_table.py > $OUT/config_table.json 2>> $OUT/log.txt || echo "config table failed" | tee -a $OUT/log.txt
 echo "== train bench" | tee -a $OUT/log.txt
 python3 tools/train_bench.py --batches 128,512 --steps 10 --no-torch > $OUT/train_bench.txt 2>> $OUT/log.txt || echo "train bench failed" | tee -a $OUT/log.txt
-if [ "$1" != quick ]; then
+if [ "$MODE" != quick ]; then
     echo "== count games" | tee -a $OUT/log.txt
     python3 bench.py --count-games 240 > $OUT/count_games.json 2>> $OUT/count_games.log || echo "count games failed" | tee -a $OUT/log.txt
 fi
