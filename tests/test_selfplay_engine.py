@@ -147,3 +147,61 @@ def test_forced_opening_book_needs_15x15():
     import pytest
     with pytest.raises(ValueError):
         SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=1, n_playout=5)
+
+
+def test_laned_evaluator_routes_slots_to_lanes():
+    """policy_value_net.LanedEvaluator (one evaluator handle per pipeline group): slot s runs on lane s mod k with the
+    lane's own slot s div k; shapes must agree; weight changes reach every lane.  Stand-in lanes: no GPU."""
+    from alphapig_amd.policy_value_net import LanedEvaluator
+
+    class Lane(object):
+        n_slots, batchsize, hw, code_stride = 3, 32, 64, 80
+
+        def __init__(self, name):
+            self.name, self.calls, self.prm = name, [], None
+
+        def evaluate_codes(self, codes):
+            self.calls.append(("eval", len(codes)))
+            return self.name
+
+        def evaluate_codes_slot(self, slot, codes):
+            self.calls.append(("eval_slot", slot, len(codes)))
+            return self.name
+
+        def submit_codes_slot(self, slot, codes):
+            self.calls.append(("submit", slot, len(codes)))
+            return len(codes)
+
+        def wait_slot(self, slot, n):
+            self.calls.append(("wait", slot, n))
+            return self.name
+
+        def set_params(self, prm, **kw):
+            self.prm = prm
+
+        def sync(self):
+            self.calls.append(("sync",))
+
+        def close(self):
+            self.calls.append(("close",))
+
+    a, b = Lane("a"), Lane("b")
+    ev = LanedEvaluator([a, b])
+    assert (ev.n_slots, ev.batchsize, ev.hw, ev.code_stride) == (3, 32, 64, 80)
+    codes = np.zeros((5, 80), np.uint8)
+    assert ev.submit_codes_slot(0, codes) == 5 and ev.wait_slot(0, 5) == "a"
+    assert ev.submit_codes_slot(1, codes) == 5 and ev.wait_slot(1, 5) == "b"
+    assert ev.evaluate_codes_slot(2, codes) == "a" and ev.evaluate_codes_slot(3, codes) == "b"
+    assert a.calls == [("submit", 0, 5), ("wait", 0, 5), ("eval_slot", 1, 5)]
+    assert b.calls == [("submit", 0, 5), ("wait", 0, 5), ("eval_slot", 1, 5)]
+    ev.set_params({"w": 1})
+    assert a.prm == {"w": 1} and b.prm == {"w": 1}
+    ev.sync()
+    ev.close()
+    assert a.calls[-2:] == [("sync",), ("close",)] and b.calls[-2:] == [("sync",), ("close",)]
+    c = Lane("c")
+    c.batchsize = 16
+    with pytest.raises(ValueError):
+        LanedEvaluator([a, c])
+    with pytest.raises(ValueError):
+        LanedEvaluator([])
