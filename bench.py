@@ -284,7 +284,7 @@ def train_step_line(device, steps=10, warmup=3):
     return out
 
 
-def config2_line(device, steps=4000, warmup=50):
+def config2_line(device, steps=6000, warmup=800):
     """BASELINE configs[1] (the metric's CPU-runnable sibling: 64 concurrent 8x8 games, 4 in a row, n_playout 200, the 6-conv
     net) through the same engine: leaf evaluations per second.  An EXTRA object (tests/config_table.py is the same measurement)."""
     from alphapig_amd.policy_value_net import LanedEvaluator, PolicyValueNet
