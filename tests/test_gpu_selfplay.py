@@ -345,6 +345,10 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launcher"] == "self-spawned" and d["valid"] is False
     assert len(d["per_rank_leaf_evals_per_s"]) == 2 and min(d["per_rank_leaf_evals_per_s"]) > 1000
     assert d["leaf_evals_per_s"] > 2000 and d["config"]["games_per_gpu"] == 256 and d["roofline"]["frac"] > 0.0   # (the two ranks' kernels share the GPU)
+    # the N > 1 line measures the round's exchange with a payload: 256 games x mean plies rows per rank, both ranks' rows verified
+    ex = d["exchange"]
+    assert ex["payload_verified"] is True and ex["ranks_seen"] == 2 and ex["rows_per_rank"] == int(round(256 * d["config"]["mean_plies_per_game"]))
+    assert ex["bytes_gathered_per_rank"] == 2 * ex["rows_per_rank"] * 1144 and ex["ms"] > 0 and "cpu_baseline" in d
 
 
 def test_two_rank_training_pipeline_with_the_real_trainer(tmp_path):
