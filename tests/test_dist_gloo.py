@@ -199,3 +199,17 @@ def test_bench_eight_self_spawned_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["launcher"] == "self-spawned" and d["scaling"] == "weak"
     assert d["host_threads_per_rank"] == max(1, min(16, d["host_cpu_share"] // 8))
+
+
+def test_bench_exchange_probe_child_process_protocol():
+    """The N = 1 line's `exchange` object: bench.exchange_probe_world1 forms a one-rank process group in a CHILD process (gloo
+    here, RCCL on the GPU box), runs dist.measure_exchange and hands the verified figures back; a child that does not
+    answer in time costs this object, not the line."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    ex = bench.exchange_probe_world1(3000, timeout_s=120.0)
+    assert ex.get("payload_verified") is True and ex["ranks_seen"] == 1 and ex["rows_per_rank"] == 3000
+    assert ex["bytes_sent_per_rank"] == 3000 * 1144 and ex["process"].startswith("child process")
+    late = bench.exchange_probe_world1(3000, timeout_s=0.01)
+    assert "error" in late and "did not answer" in late["error"]
