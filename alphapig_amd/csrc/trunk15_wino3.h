@@ -114,15 +114,7 @@ __device__ __forceinline__ float wino3_row16_sum(float v) {
     return wino3_dpp_add<0x140>(v);   // row_mirror: the other 8 of the 16
 }
 
-// BW (round 5, "a board per wave"): the same work item (board pair x 64 output channels x 36 positions), the same transform,
-// staging, chunk stream and packed weights, but wave w = (16-channel tile w & 3, BOARD w >> 2) with ALL 36 positions of that
-// board (36 x 4 = 144 accumulators) instead of (tile, row half) with both boards.  A slot is then four positions of one
-// board (one f32x4 weight piece, two position pairs of V); the two board waves of a tile -- the two waves of one SIMD -- fetch
-// the same weight pieces (the second read is an L1 hit).  What it buys: every (channel, tile) has its six rows of M in ONE
-// lane, so the output transform needs no exchange through LDS and the epilogue NO workgroup barrier (eight per item before).
-// The same MFMA order per accumulator and the same output formulas (row partials lo / hi, then y0 = lo0 + hi0, ...): the same
-// bits as the row-half form.  Not with QUARTER or STATS.
-template <bool RESID, bool RELU = true, bool QUARTER = false, bool STATS = false, bool BW = false>
+template <bool RESID, bool RELU = true, bool QUARTER = false, bool STATS = false>
 __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restrict__ in, const float* __restrict__ upk,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out,
@@ -187,7 +179,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESID ? resid : in), 0, act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, act_bytes, 0x00020000);
     static_assert(!STATS || (!RESID && !RELU), "STATS: the training forward (bias only)");
-    static_assert(!BW || (!QUARTER && !STATS), "BW: 64-channel items of the inference / data-gradient forms only");
     const __amdgpu_buffer_rsrc_t r_st =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(STATS ? resid : in), 0, STATS ? (unsigned)n * T::C * 16u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, T::C * 4, 0x00020000);
@@ -335,17 +326,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
     const unsigned ulane = lane * (T::UROW * 4);
     auto uload = [&](int ks, int v) {           // ks = global k-step of this workgroup's stream (32 per item), v = piece 0..4
         const int hh = item_half(ks >> 5), kk = ks & 31;
-        if constexpr (BW) {
-            // entry v = 0..9 of the k-step in slot order: row half 0 pieces 0..4, row half 1 piece 4, row half 1 pieces 0..3
-            const int half = v >= 5, piece = v < 5 ? v : (v == 5 ? 4 : v - 6);
-            const unsigned so = (unsigned)(((4 * hh + ct) * 2 + half) * 32 + kk) * (T::USTEP * 4);
-            if (piece == 4) {
-                const auto w = __builtin_amdgcn_raw_buffer_load_b64(r_u, ulane + 64, so, 0);
-                const f32x2 f = __builtin_bit_cast(f32x2, w);
-                return f32x4{f[0], f[1], 0.f, 0.f};
-            }
-            return bload(r_u, ulane + piece * 16, so);
-        }
         const unsigned so = (unsigned)((((QUARTER ? 2 : 4) * hh + ct) * 2 + ph) * 32 + kk) * (T::USTEP * 4);
         if (v == 4) {                           // values 16, 17 (+ 2 pad floats that are never loaded: dead registers under an
             const auto w = __builtin_amdgcn_raw_buffer_load_b64(r_u, ulane + 64, so, 0);   // in-flight load get reused -> WAW waits)
@@ -386,9 +366,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #if APZ3_EARLY_BARRIER
     __syncthreads();                                // V[0] (chunk 0) complete
     {
-        const float* vp0 = vb + (BW ? 0 : 9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0) + (BW ? ph * 256 : 0);
+        const float* vp0 = vb + (9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0);
         bc0 = *reinterpret_cast<const f32x2*>(vp0);
-        if (!QUARTER) bc1 = *reinterpret_cast<const f32x2*>(vp0 + (BW ? T::VPP : 256));
+        if (!QUARTER) bc1 = *reinterpret_cast<const f32x2*>(vp0 + 256);
     }
 #endif
     for (int t = 0; t < nitems; t++) {
@@ -432,55 +412,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
 #endif
         auto chunk = [&](int g, auto PAR) {
             constexpr int par = decltype(PAR)::value;
-            const float* vp = vb + par * T::V_FLOATS + (BW ? 0 : 9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0) + (BW ? ph * 256 : 0);   // QUARTER / BW: own board only
+            const float* vp = vb + par * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0);   // QUARTER: own board only
             // APZ3_EARLY_BARRIER: the chunk's barrier sits between slots 16 and 17 of the PREVIOUS chunk (see there) and
             // bc0 / bc1 already hold this chunk's first operands.
-            const float* vpn = vb + (1 - par) * T::V_FLOATS + (BW ? 0 : 9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0) + (BW ? ph * 256 : 0);
+            const float* vpn = vb + (1 - par) * T::V_FLOATS + (9 * ph) * T::VPP + (q * 16 + j) * 2 + (QUARTER ? bsel * 256 : 0);
 #if !APZ3_EARLY_BARRIER
             __syncthreads();                    // V[par] complete, V[1-par] and raw[par] free, raw[1-par] visible
             APZ3_STAMP(1)
             bc0 = *reinterpret_cast<const f32x2*>(vp);
             if (!QUARTER) bc1 = *reinterpret_cast<const f32x2*>(vp + 256);
 #endif
-            // BW: slot m of a k-step = four positions of this wave's board: position pairs (ppa, ppb) = (2m, 2m + 1) for
-            // m < 4 (row half 0), (8, 17) for m = 4 (the last pair of either half), (2m - 1, 2m) for m > 4 (row half 1);
-            // weight entry 0..9 (uload) in ring quad entry % 5: slot m uses quad m (m <= 4; m = 4 also quad 0 = entry 5),
-            // quad m - 4 (m > 4); a quad is refilled right behind its last MFMA with the entry five further on
-#define APZ3_BW_PPA(m) ((m) < 4 ? 2 * (m) : ((m) == 4 ? 8 : 2 * (m) - 1))
-#define APZ3_BW_PPB(m) ((m) < 4 ? 2 * (m) + 1 : ((m) == 4 ? 17 : 2 * (m)))
-#define APZ3_SLOT_BW(k)                                                                                            \
-            {                                                                                                      \
-                constexpr int s = (k) / 9, m = (k) % 9, sn = ((k) + 1) / 9, mn = ((k) + 1) % 9;                        \
-                constexpr int ppa = APZ3_BW_PPA(m), ppb = APZ3_BW_PPB(m);                                           \
-                f32x2 bn0 = bc0, bn1 = bc1;                                                                        \
-                if ((k) + 1 < 18) {                                                                                \
-                    bn0 = *reinterpret_cast<const f32x2*>(vp + APZ3_BW_PPA(mn) * T::VPP + sn * 128);               \
-                    bn1 = *reinterpret_cast<const f32x2*>(vp + APZ3_BW_PPB(mn) * T::VPP + sn * 128);               \
-                } else if (APZ3_EARLY_BARRIER) {          /* the next chunk's first operands (V[1-par], complete) */ \
-                    bn0 = *reinterpret_cast<const f32x2*>(vpn);                                                    \
-                    bn1 = *reinterpret_cast<const f32x2*>(vpn + T::VPP);                                           \
-                }                                                                                                  \
-                constexpr int qa = m <= 4 ? m : m - 4, qb = m == 4 ? 0 : qa;   /* ring quads of positions 0,1 / 2,3 */ \
-                const float a0 = ur[qa][0], a1 = ur[qa][1], a2 = ur[qb][m == 4 ? 0 : 2], a3 = ur[qb][m == 4 ? 1 : 3]; \
-                constexpr int ha = ppa / 9, ia = 2 * (ppa % 9), hb = ppb / 9, ib = 2 * (ppb % 9);                   \
-                acc[ha][ia] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc0[0], acc[ha][ia], 0, 0, 0);              \
-                acc[ha][ia + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc0[1], acc[ha][ia + 1], 0, 0, 0);      \
-                acc[hb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bc1[0], acc[hb][ib], 0, 0, 0);              \
-                acc[hb][ib + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bc1[1], acc[hb][ib + 1], 0, 0, 0);      \
-                APZ3_BODY_STAGING(k)                                                                               \
-                if constexpr (m < 4) ur[m] = uload(2 * g + s, m + 5);                                              \
-                else if constexpr (m == 4) {                                                                       \
-                    ur[4] = uload(2 * g + s, 9);                                                                   \
-                    ur[0] = uload(2 * g + s + 1, 0);                                                               \
-                } else ur[m - 4] = uload(2 * g + s + 1, m - 4);                                                    \
-                bc0 = bn0;                                                                                         \
-                bc1 = bn1;                                                                                         \
-                if (APZ3_EARLY_BARRIER && (k) == 16) {                                                             \
-                    __syncthreads();                                                                               \
-                    APZ3_STAMP(1)                                                                                  \
-                }                                                                                                  \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-            }
 #define APZ3_SLOT(k)                                                                                               \
             {                                                                                                      \
                 constexpr int s = (k) / 9, m = (k) % 9, sn = ((k) + 1) / 9, mn = ((k) + 1) % 9;                        \
@@ -512,13 +453,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 }                                                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
             }
-            if constexpr (BW) {
-                APZ3_ALL18(APZ3_SLOT_BW)
-            } else {
-                APZ3_ALL18(APZ3_SLOT)
-            }
+            APZ3_ALL18(APZ3_SLOT)
 #undef APZ3_SLOT
-#undef APZ3_SLOT_BW
             APZ3_STAMP(2)
         };
         for (int c = 0; c < T::NCHUNK; c += 2) {
@@ -553,34 +489,6 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         // rows of this wave -> (P0, P1, P2) for TWO channels at once: components r0, r0 + 1 of an accumulator are
         // neighbouring registers, so the whole k-direction transform (the formulas above) and the row sums run as
         // packed two-wide operations -- half the VALU instructions of the epilogue's biggest part
-        auto partial2h = [&](const f32x4* a, auto R0, auto HALF, f32x2 (*p)[4]) {   // ... for the rows of half HALF
-            constexpr int r0 = decltype(R0)::value, half = decltype(HALF)::value;
-            f32x2 hh[3][4];
-#pragma unroll
-            for (int ii = 0; ii < 3; ii++) {
-                f32x2 m[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) m[k] = __builtin_shufflevector(a[ii * 6 + k], a[ii * 6 + k], r0, r0 + 1);
-                const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-                hh[ii][0] = (m[0] + s12) + s34;
-                hh[ii][1] = fma2(2.f, d34, d12);
-                hh[ii][2] = fma2(4.f, s34, s12);
-                hh[ii][3] = fma2(8.f, d34, d12) + m[5];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (half == 0) {
-                    const f32x2 s12 = hh[1][e] + hh[2][e];
-                    p[0][e] = hh[0][e] + s12;
-                    p[1][e] = hh[1][e] - hh[2][e];
-                    p[2][e] = s12;
-                } else {
-                    p[0][e] = hh[0][e] + hh[1][e];
-                    p[1][e] = hh[0][e] - hh[1][e];
-                    p[2][e] = hh[2][e];
-                }
-            }
-        };
         auto partial2 = [&](const f32x4* a, auto R0, f32x2 (*p)[4]) {
             constexpr int r0 = decltype(R0)::value;
             f32x2 hh[3][4];
@@ -609,73 +517,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
                 }
             }
         };
-        if constexpr (BW) {
-            // ---- BW epilogue: this wave holds all six rows of M of board ph for channels cot*16 + 4q + r and tile j.
-            // lo = the row partial of rows 0..2 (acc[0]), hi = that of rows 3..5 (acc[1]) -- the very values the row-half
-            // form exchanges through X -- then the same y formulas.  No LDS but the wave-private staging area, no barrier.
-            f32x4 winb[2][4];
-            auto resid_load = [&](int r) {
-#pragma unroll
-                for (int qp = 0; qp < 4; qp++) winb[r & 1][qp] = bload(r_res, ep_vo, plane_so(r, qp));
-            };
-            auto step_bw = [&](int r, int sub, f32x2 (*lo)[4], f32x2 (*hi)[4]) {
-                APZ3_STAMP(3)
-                if (RESID && r >= 1 && r + 1 < 4) resid_load(r + 1);     // one step ahead (steps 0 and 1: before step 0)
-                f32x4 (&win)[4] = winb[r & 1];
-                f32x4 w4[4];
-                if (RESID) {                    // plane pieces -> staging -> this lane's 4x4 patch
-#pragma unroll
-                    for (int qp = 0; qp < 4; qp++) *reinterpret_cast<f32x4*>(sw + qp * T::SPLANE + s_lin) = win[qp];
-                    APZ3_FENCE();
-#pragma unroll
-                    for (int a = 0; a < 4; a++) w4[a] = *reinterpret_cast<const f32x4*>(sw + s_own + a * T::SROW);
-                    APZ3_FENCE();
-                    APZ3_STAMP(5)
-                }
-                const float bvr = bv[r];
-                f32x4 y[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float lo0 = lo[0][e][sub], lo1 = lo[1][e][sub], lo2 = lo[2][e][sub];
-                    const float hi0 = hi[0][e][sub], hi1 = hi[1][e][sub], hi2 = hi[2][e][sub];
-                    y[0][e] = lo0 + hi0;
-                    y[1][e] = __builtin_fmaf(2.f, hi1, lo1);
-                    y[2][e] = __builtin_fmaf(4.f, hi0, lo2);
-                    y[3][e] = lo1 + __builtin_fmaf(8.f, hi1, hi2);
-                }
-#pragma unroll
-                for (int a = 0; a < 4; a++) {
-                    f32x4 v = y[a] + bvr;
-                    if (RESID) v += w4[a];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) y[a][e] = RELU ? fmaxf(v[e], 0.f) : v[e];
-                    if (etx == 3) y[a][3] = 0.f;   // column 15 is the halo column of the rows16 layout
-                    *reinterpret_cast<f32x4*>(sw + s_own + a * T::SROW) = y[a];
-                }
-                APZ3_FENCE();
-                f32x4 pv[4];
-#pragma unroll
-                for (int qp = 0; qp < 4; qp++) pv[qp] = *reinterpret_cast<const f32x4*>(sw + qp * T::SPLANE + s_lin);
-                APZ3_FENCE();
-                APZ3_STAMP(3)
-#pragma unroll
-                for (int qp = 0; qp < 4; qp++) bstore(r_out, st_out_vo, plane_so(r, qp), pv[qp]);
-                APZ3_STAMP(6)
-            };
-            f32x2 lo[3][4], hi[3][4];
-            partial2h(acc[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lo);
-            partial2h(acc[1], std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, hi);
-            if (RESID) {                        // (72 accumulator registers are dead by now)
-                resid_load(0);
-                resid_load(1);
-            }
-            step_bw(0, 0, lo, hi);
-            step_bw(1, 1, lo, hi);
-            partial2h(acc[0], std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, lo);
-            partial2h(acc[1], std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, hi);
-            step_bw(2, 0, lo, hi);
-            step_bw(3, 1, lo, hi);
-        } else {
+        {
             constexpr int own = ph;             // static register indices
             f32x4 winb[2][4];                   // residual planes in flight: step r in winb[r & 1]
             // QUARTER: sub-step r of a (tile, board) is finished by the row-half wave ph = (r >= 2); the other one only sends
@@ -827,11 +669,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
         APZ3_STAMP(6)
 #if APZ3_EARLY_BARRIER
         // the next item's first barrier comes only after its slot 16, and its transform slices write V[1] (= X) from
-        // slot 10 on: every wave must have read its last X values before anybody goes on (BW: no X, no barrier)
-        if constexpr (!BW) {
-            __syncthreads();
-            APZ3_STAMP(4)
-        }
+        // slot 10 on: every wave must have read its last X values before anybody goes on
+        __syncthreads();
+        APZ3_STAMP(4)
 #endif
     }
     };
