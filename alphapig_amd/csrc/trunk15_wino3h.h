@@ -1,0 +1,533 @@
+// Trunk 3x3 convolution (128 -> 128 channels, 15x15 board) + folded BN + (residual) + ReLU as a fused F(4x4,3x3)
+// Winograd convolution whose 36 per-position GEMMs run on the FP16 matrix pipe at fp32-level accuracy: every fp32 operand
+// is split into TWO fp16 terms (x = hi + lo, 11 significant bits each, both rounded to nearest even: |x - hi - lo| <=
+// 2^-22 |x| while lo is a normal fp16 number, <= 2^-25 absolute below that) and a product is the three term products
+// hi.hi + hi.lo + lo.hi (+ lo.lo, which rides along for free), accumulated in fp32 by the MFMA.  gfx950 only.
+// Successor of trunk15_wino3b.h (three bf16 terms, six products): half the matrix instructions, a third fewer weight
+// bytes, a third fewer LDS fragment reads and half the split's vector instructions (round 6; profiles/r06_wino3h.md).
+//
+// Range.  fp16 holds 6.1e-5 .. 65504 in normal numbers, so both operands are placed by powers of two:
+//   * weights: U = G g G^T of output channel co is multiplied by S[co] = 2^k chosen on the host / by the device packer
+//     so that max |U S| sits in [2^13, 2^14); the epilogue multiplies by 1 / S[co] (exact) inside the bias FMA.
+//   * activations: V = B^T d B is NOT scaled.  |V| <= 100 max|d|: post-ReLU activations up to 655 are representable;
+//     values below 2^-3 keep an absolute error of 2^-25.  An input that does overflow gives +-inf / NaN in the
+//     accumulators; the epilogue checks every pre-ReLU value (a NaN would otherwise be clamped to 0 silently) and raises
+//     `flag[0]`, on which the engine repeats the forward on the exact-fp32 kernel (apz_engine.hip).
+//
+// Shape: trunk15_wino3b.h's, unchanged (read its header for the measured reasons) -- work item = (board pair, 64 output
+// channels, all 36 positions); eight waves, two per SIMD; wave = (32-channel half, 3x3 position block) with 9 x 16 = 144
+// accumulator registers; 16 chunks of 8 input channels per item, one barrier per chunk; raw planes by LDS-DMA, the input
+// transform B^T d B (fp32 VALU) by all 512 threads in 18 slices between the MFMAs; weights straight from L2 into a
+// register ring.  What changed:
+//   * K packing.  One v_mfma_f32_32x32x16_f16 contracts k = 16 = 8 channels x 2 weight terms:
+//         A = [Whi | Wlo] (lanes 0-31 hold k = 0-7, lanes 32-63 k = 8-15), B = [Vt | Vt] for t = lo, then t = hi:
+//     two MFMAs per (position, 32 output channels, 8 input channels) instead of three, ONE 16-byte weight load per lane
+//     and unit (1 KB per wave, fully coalesced; 4 bytes per weight as in the fp32 kernel), two V fragments per position.
+//   * The split: hi = v_cvt_pk_f16_f32 of (my value, my pair partner's), remainder = v_fma_mix_f32 (exact), lo =
+//     v_cvt_pk_f16_f32 of the remainders: 4 vector instructions per position and channel pair (bf16 x 3: 11).  Odd lanes
+//     pack their own (odd) channel into the low half: for positions k = 3..5 of a row the two channels of a pair are
+//     swapped in V -- and in the packed weights (upk_offset), so the contraction pairs them up again.
+//
+// Layouts.  in / resid / out: rows16 [n][128][15][16] (col 15 == 0).  raw (LDS): as Wino3B.  V (LDS): [pos 36][term 2]
+// [col 32][8 ch] fp16, col = board * 16 + tile: a B fragment is ONE conflict-free ds_read_b128 (both lane halves read the
+// same 16 bytes).  upk: [cog 4][block 4][chunk 16][position 9][term 2][co 32][8 ch] fp16.  bias: [128 bias][128 1/S].
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "trunk15_wino3.h"
+
+namespace apz {
+
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct Wino3H {
+    static constexpr int C = 128, CK = 8, NCHUNK = C / CK;             // 16 chunks of 8 input channels
+    static constexpr int GPLANE = 240;
+    // raw input tile: as Wino3B (planes as in HBM + two zero rows behind each; plane stride 272 floats)
+    static constexpr int RROW = 16, RPS = 17 * RROW, RFRONT = 32;
+    static constexpr int RAW_FLOATS = RFRONT + 2 * CK * RPS + 32;      // 4416 floats (17.3 KiB)
+    static constexpr int VTERM = 32 * 16, VPOS = 2 * VTERM, V_BYTES = 36 * VPOS;   // 512, 1024, 36864 bytes
+    static constexpr int MAIN_BYTES = 2 * RAW_FLOATS * 4 + 2 * V_BYTES; // 109056
+    static constexpr int UNIT = 2 * 32 * 16;                           // bytes of one (cog, block, chunk, position): 1024
+    static constexpr size_t UPK_BYTES = (size_t)4 * 4 * NCHUNK * 9 * UNIT;         // 2.36 MB per layer
+    static constexpr int BIAS_FLOATS = 256;                            // [bias 128][1 / S 128]
+    // epilogue: M and the store staging alias the two V buffers (and what lies behind them); the raw tiles stay untouched
+    static constexpr int MQ_FLOATS = 36 * 16 * 32;                     // 73728 bytes at the V base
+    static constexpr int SROW = 20, SPLANE = 16 * SROW;                // staging plane: 16 rows x 20 floats
+    static constexpr int STG_FLOATS = 8 * 4 * SPLANE;                  // 8 waves x 4 planes (40 KiB)
+    static constexpr int LDS_BYTES = 2 * RAW_FLOATS * 4 + (MQ_FLOATS + STG_FLOATS) * 4;   // 150016
+    static_assert(LDS_BYTES >= MAIN_BYTES, "epilogue area covers V");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    // byte offset of element (co, ci, pos, term) in the packed weights
+    __host__ __device__ static size_t upk_offset(int co, int ci, int pos, int term) {
+        const int i = pos / 6, k = pos % 6, ri = i / 3, ki = k / 3, p9 = 3 * (i % 3) + (k % 3);
+        const int cog = co >> 5, r = co & 31, chunk = ci >> 3, w = 2 * ri + ki;
+        const int ch = (ci & 7) ^ (k >= 3 ? 1 : 0);                    // positions packed by the odd lanes: pair swapped
+        return ((((size_t)(cog * 4 + w) * NCHUNK + chunk) * 9 + p9) * 2 + term) * VTERM + r * 16 + ch * 2;
+    }
+    // the power of two that puts m = max |U| of an output channel into [2^13, 2^14) (m == 0: 1)
+    __host__ __device__ static float scale_for(double m) {
+        if (!(m > 0.0)) return 1.f;
+        int e;
+        frexp(m, &e);                                                  // m = f 2^e, f in [0.5, 1)
+        int k = 14 - e;
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+        return (float)ldexp(1.0, k);
+    }
+};
+
+// Host packing: U[pos][co][ci] (double) -> the kernel's fp16 x 2 layout + the per-channel inverse scales.
+// `u_of(co, ci, pos)` returns the value.  inv_scale: 128 floats (goes behind the 128 biases).
+template <class F>
+inline void wino3h_pack_host(F u_of, std::vector<uint16_t>& out, float* inv_scale) {
+    out.assign(Wino3H::UPK_BYTES / 2, 0);
+    for (int co = 0; co < 128; co++) {
+        double m = 0;
+        for (int ci = 0; ci < 128; ci++)
+            for (int pos = 0; pos < 36; pos++) m = std::max(m, std::fabs((double)u_of(co, ci, pos)));
+        const float S = Wino3H::scale_for(m);
+        inv_scale[co] = 1.f / S;
+        for (int ci = 0; ci < 128; ci++)
+            for (int pos = 0; pos < 36; pos++) {
+                const double x = (double)u_of(co, ci, pos) * (double)S;
+                const _Float16 hi = (_Float16)(float)x;
+                const _Float16 lo = (_Float16)(float)(x - (double)(float)hi);
+                uint16_t hb, lb;
+                std::memcpy(&hb, &hi, 2);
+                std::memcpy(&lb, &lo, 2);
+                out[Wino3H::upk_offset(co, ci, pos, 0) / 2] = hb;
+                out[Wino3H::upk_offset(co, ci, pos, 1) / 2] = lb;
+            }
+    }
+}
+
+#ifdef APZ_WINO3H_STAMPS
+__device__ unsigned long long apz_wino3h_stamps[4 * 8 * 8];   // [workgroup 4][wave 8][phase 8]
+#endif
+
+#ifndef APZH_RING
+#define APZH_RING 6          /* weight units in registers (RING - 1 in flight); 6 or 9 */
+#endif
+
+template <bool RESID, bool RELU = true>
+__global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __restrict__ in, const void* __restrict__ upk,
+                                                             const float* __restrict__ bias, const float* __restrict__ resid,
+                                                             float* __restrict__ out, int n, unsigned* __restrict__ flag) {
+    using T = Wino3H;
+#ifdef APZ_WINO3H_STAMPS
+    // phases: 0 item prologue, 1 barrier waits, 2 chunk bodies, 3 epilogue, 7 total
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_readcyclecounter();
+    const unsigned long long st_t0 = st_t;
+#define APZH_STAMP(ph_)                                               \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        st_acc[ph_] += now_ - st_t;                                   \
+        st_t = now_;                                                  \
+    }
+#else
+#define APZH_STAMP(ph_)
+#endif
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* rawb = lds;                                                    // [2][RAW_FLOATS]
+    char* vbase = reinterpret_cast<char*>(lds + 2 * T::RAW_FLOATS);       // [2][V_BYTES]
+    float* mq = lds + 2 * T::RAW_FLOATS;                                  // epilogue: M[pos 36][co 16][col 32] (over V)
+    float* stg = mq + T::MQ_FLOATS;                                       // epilogue: [wave 8][plane 4][16 x 20]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- work items: as trunk15_wino3_kernel (duo mode: blocks b and b + 8 take the two channel halves of the same pairs)
+    const int npairs = (n + 1) >> 1, G_ = (int)gridDim.x, b_ = (int)blockIdx.x;
+    const bool duo = (G_ & 15) == 0;
+    const int pair0 = duo ? ((b_ >> 4) * 8 + (b_ & 7)) : b_;
+    const int pstride = duo ? (G_ >> 1) : G_;
+    const int h_fix = (b_ >> 3) & 1;
+    const int np = pair0 < npairs ? (npairs - pair0 + pstride - 1) / pstride : 0;
+    const int nitems = duo ? np : 2 * np;
+    if (np == 0) return;
+    auto item_pair = [&](int t) { return pair0 + (duo ? t : (t >> 1)) * pstride; };
+    auto item_half = [&](int t) { return duo ? h_fix : (t & 1); };
+
+    const unsigned plane_b = T::GPLANE * 4;
+    const unsigned act_bytes = (unsigned)n * T::C * plane_b;
+    const __amdgpu_buffer_rsrc_t r_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESID ? resid : in), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_u =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(upk), 0, (unsigned)T::UPK_BYTES, 0x00020000);
+    auto bload = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    auto bstore = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, const f32x4 v) {   // soffset = 0: see trunk15_wino3.h
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, 0);
+    };
+
+    // ---- staging role: wave w brings planes w (board 0) and w + 8 (board 1) of a chunk into LDS by LDS-DMA
+    // (buffer_load_dwordx4 ... lds; lanes 60..63 out of range: row 15 of the tile stays zero).  Inline assembly: hipcc's
+    // wait-count insertion does not see these loads.  They need no wait of their own: a plane requested in slot 1 of a
+    // chunk is older than the weight loads issued behind it, whose data the MFMAs of a later slot wait for -- vector memory
+    // operations complete in order -- and the tile is first read behind the next chunk's barrier.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)rawb;   // LDS byte address of rawb
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    const unsigned long long in_a = (unsigned long long)in;
+    const i32x4_ dma_rsrc = {(int)(unsigned)(in_a & 0xffffffffull), (int)(unsigned)((in_a >> 32) & 0xffffull), (int)act_bytes, 0x00020000};
+    const unsigned dma_vo = lane < 60 ? lane * 16 : 0x80000000u;
+    auto raw_dma = [&](int t, int c, int par) {       // chunk c (clamped) of item t -> raw[par]
+        c = c < T::NCHUNK ? c : T::NCHUNK - 1;
+        const int bd0_ = 2 * item_pair(t);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int plane = 8 * j + wave;           // board j, channel `wave`
+            const int bdp = bd0_ + j;
+            const int bd = bdp < n ? bdp : n - 1;
+            const unsigned so = (unsigned)(bd * T::C + c * T::CK + wave) * plane_b;
+            const unsigned dst = lds0 + (unsigned)(par * T::RAW_FLOATS + T::RFRONT + plane * T::RPS) * 4;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(dma_vo), "s"(dma_rsrc), "s"(dst), "s"(so) : "memory");
+        }
+    };
+
+    // ---- MFMA role: 32-channel half cc of the item's 64, position block (ri, ki)
+    const int cc = wave >> 2, ri = (wave >> 1) & 1, ki = wave & 1, blk = wave & 3;
+    const int r31 = lane & 31, hh = lane >> 5;
+    const unsigned a_vo = lane * 16;                  // A = [Whi | Wlo]: lanes 0-31 the hi terms of their channel, 32-63 the lo terms
+    const int wpos0 = 18 * ri + 3 * ki;               // first position of this wave's block
+    auto pos_off = [](int p9) { return (6 * (p9 / 3) + (p9 % 3)) * T::VPOS; };   // position p9 of the block, relative to wpos0
+
+    // weight stream: unit index of this wave = (item t * 16 + chunk c) * 9 + p9
+    static constexpr int RING = APZH_RING;
+    static_assert(RING == 6 || RING == 9, "ring slots must tile two chunks");
+    f16x8 af[RING];
+    auto unit_load = [&](int t, int c, int p9, int slot) {
+        // (c, p9) may run past the end of the item: carry into the next item; past the last item: reload the last unit
+        if (p9 >= 9) { p9 -= 9; c += 1; }
+        if (c >= T::NCHUNK) { c -= T::NCHUNK; t += 1; }
+        if (t >= nitems) { t = nitems - 1; c = T::NCHUNK - 1; p9 = 8; }
+        const int cog = 2 * item_half(t) + cc;
+        const unsigned so = (unsigned)(((cog * 4 + blk) * T::NCHUNK + c) * 9 + p9) * T::UNIT;
+        af[slot] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_u, a_vo, so, 0));
+    };
+
+    unsigned nonfinite = 0;                           // any pre-ReLU output of this thread that is not a finite number
+
+    // Everything that depends on the row half of the transform role is instantiated twice (wave-uniform branch below)
+    auto run = [&](auto PH) {
+        constexpr int ph = decltype(PH)::value;
+        // ---- transform role: board tb, row half ph, channels 4 ch4 .. 4 ch4 + 3.  lane -> (tile row tty, tile column
+        // ttx, channel); bit 0 = channel parity e: the two channels of a pair are DPP neighbours (trunk15_wino3b.h).
+        const int tb = wave & 1, ch4 = wave >> 2;
+        const int e = lane & 1, run4 = (lane >> 2) & 7;
+        const int ttx = 2 * ((run4 >> 1) & 1) + ((lane >> 1) & 1), cpl = run4 >> 2;
+        const int tty = 2 * (lane >> 5) + 1 - ((0x69 >> run4) & 1);
+        const int tile = 4 * tty + ttx, chl = 4 * ch4 + 2 * cpl + e;          // channel of the chunk (0..7)
+        const int tr_off = T::RFRONT + (tb * 8 + chl) * T::RPS + (4 * tty - 1 + ph) * T::RROW + 4 * ttx;
+        const unsigned col16_mask = ttx == 3 ? 0u : 0xffffffffu;   // column 16 does not exist: the word there is column 0 of the next row
+        // bytes: column tb * 16 + tile, dword = channel pair; even lanes pack positions k = 0..2 of a row, odd lanes 3..5
+        const int tv_off = tb * 256 + tile * 16 + (2 * ch4 + cpl) * 4 + e * 3 * T::VPOS;
+        float xr[5][4];                                // five patch rows of the channel: four columns at a time
+        float tt[3][6];                                // row-pass results (rows 3 ph .. 3 ph + 2), columns -1 .. 4
+        float oo[6];
+        auto row_pass = [&](const float* rp, auto PART) {
+            constexpr int part = decltype(PART)::value;
+            constexpr int nc = part == 0 ? 4 : 2;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (part == 0) {
+                    const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
+                    xr[i][0] = c03[0]; xr[i][1] = c03[1]; xr[i][2] = c03[2]; xr[i][3] = c03[3];
+                } else {
+                    xr[i][0] = rp[i * T::RROW - 1];
+                    xr[i][1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rp[i * T::RROW + 4]) & col16_mask);   // (no branch)
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < nc; k++) {
+                const int kc = part == 0 ? k + 1 : 5 * k;      // column index in tt (0 = column -1, 5 = column 4)
+                if (ph == 0) {                         // x = patch rows 0..4: y0 = 4x0 - 5x2 + x4, y1/y2 = (x4 - 4x2) +- (x3 - 4x1)
+                    const float a = __builtin_fmaf(-4.f, xr[2][k], xr[4][k]), b = __builtin_fmaf(-4.f, xr[1][k], xr[3][k]);
+                    tt[0][kc] = __builtin_fmaf(4.f, xr[0][k], __builtin_fmaf(-5.f, xr[2][k], xr[4][k]));
+                    tt[1][kc] = a + b;
+                    tt[2][kc] = a - b;
+                } else {                               // z = patch rows 1..5: y3/y4 = (z3 - z1) +- 2(z2 - z0), y5 = 4z0 - 5z2 + z4
+                    const float c = xr[3][k] - xr[1][k], d = xr[2][k] - xr[0][k];
+                    tt[0][kc] = __builtin_fmaf(2.f, d, c);
+                    tt[1][kc] = __builtin_fmaf(-2.f, d, c);
+                    tt[2][kc] = __builtin_fmaf(4.f, xr[0][k], __builtin_fmaf(-5.f, xr[2][k], xr[4][k]));
+                }
+            }
+        };
+        auto col_pass = [&](const float* v, float* o) {   // B^T over the columns of one row
+            const float a = __builtin_fmaf(-4.f, v[2], v[4]), b = __builtin_fmaf(-4.f, v[1], v[3]);
+            const float c = v[4] - v[2], d = v[3] - v[1];
+            o[0] = __builtin_fmaf(4.f, v[0], __builtin_fmaf(-5.f, v[2], v[4]));
+            o[1] = a + b;
+            o[2] = a - b;
+            o[3] = __builtin_fmaf(2.f, d, c);
+            o[4] = __builtin_fmaf(-2.f, d, c);
+            o[5] = __builtin_fmaf(4.f, v[1], __builtin_fmaf(-5.f, v[3], v[5]));
+        };
+        // my value and my pair partner's value of one position -> two dwords of fp16 pairs (low half: mine): hi = both
+        // values rounded to fp16, lo = the remainders (exact in fp32) rounded to fp16
+        auto emit = [&](char* vp, float mine, float theirs) {
+            typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+            const f16x2_ h2 = {(_Float16)mine, (_Float16)theirs};            // v_cvt_pk_f16_f32
+            const unsigned hu = __builtin_bit_cast(unsigned, h2);
+            float rm, rt;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rm) : "v"(hu), "v"(mine));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rt) : "v"(hu), "v"(theirs));
+            const f16x2_ l2 = {(_Float16)rm, (_Float16)rt};
+            *reinterpret_cast<unsigned*>(vp) = hu;
+            *reinterpret_cast<unsigned*>(vp + T::VTERM) = __builtin_bit_cast(unsigned, l2);
+        };
+        // The transform of one chunk (raw[rpar] -> V[vpar], this thread's channel, rows 3 ph .. 3 ph + 2) in 18 slices, two
+        // per MFMA slot of a chunk body
+        float mine3[3], theirs3[3];
+        auto tslice = [&](int rpar, int vpar, auto KK) {
+            constexpr int K = decltype(KK)::value;
+            const float* rp = rawb + rpar * T::RAW_FLOATS + tr_off;
+            char* vp = vbase + vpar * T::V_BYTES + tv_off;
+            if constexpr (K == 0) row_pass(rp, std::integral_constant<int, 0>{});
+            else if constexpr (K == 1) row_pass(rp, std::integral_constant<int, 1>{});
+            else if constexpr (K >= 3 && K < 18) {
+                constexpr int ii = (K - 3) / 5, part = (K - 3) % 5;
+                if constexpr (part == 0) col_pass(tt[ii], oo);
+                else if constexpr (part == 1) {
+                    // the three values I pack myself and the three my partner packs; the partner's come over by DPP
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        mine3[k] = e ? oo[k + 3] : oo[k];
+                        const float send = e ? oo[k] : oo[k + 3];
+                        theirs3[k] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                    }
+                } else {
+                    constexpr int k = part - 2;
+                    emit(vp + ((3 * ph + ii) * 6 + k) * T::VPOS, mine3[k], theirs3[k]);
+                }
+            }
+        };
+#define APZH_ALL18(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17)
+        auto transform = [&](int rpar, int vpar) {
+#define APZH_TS(k) tslice(rpar, vpar, std::integral_constant<int, k>{});
+            APZH_ALL18(APZH_TS)
+#undef APZH_TS
+        };
+
+        // zero halo rows of both raw buffers (the DMA never touches them), once
+        for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 2048) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the first RING - 1 weight units
+#pragma unroll
+        for (int u = 0; u < RING - 1; u++) unit_load(0, 0, u, u);
+        __syncthreads();
+        raw_dma(0, 0, 0);                              // the first item's first two chunks (later items: from the epilogue before)
+        raw_dma(0, 1, 1);
+
+        for (int t = 0; t < nitems; t++) {
+            const int h = item_half(t);
+            const int bd0 = 2 * item_pair(t);
+            const bool two = bd0 + 1 < n;
+            // ---- item prologue: raw(0), raw(1) have been requested; V[0] = transform(raw(0))
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            transform(0, 0);
+            f32x16h acc[9];
+#pragma unroll
+            for (int p = 0; p < 9; p++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) acc[p][v] = 0.f;
+            APZH_STAMP(0)
+
+            // ---- chunk loop.  Iteration c: [barrier] DMA of raw(c+2) -> raw[c & 1] (read last by the transform of iteration
+            // c - 1); transform of raw[(c+1) & 1] -> V[(c+1) & 1]; MFMAs over V[c & 1]: 9 slots = the wave's 9 positions,
+            // each slot 2 MFMAs + two slices of the transform + the refill of the weight ring slot freed by the previous slot.
+            // (measurement builds of tools/wino3h_bench.hip: the chunk body without its transform / weight loads / fragment reads)
+#ifndef APZH_ABL_T
+#define APZH_ABL_T 0
+#endif
+#ifndef APZH_ABL_W
+#define APZH_ABL_W 0
+#endif
+#ifndef APZH_ABL_D
+#define APZH_ABL_D 0      /* no LDS-DMA of the next chunks' planes inside the chunk loop (stale tiles: timing only) */
+#endif
+#ifndef APZH_ABL_B
+#define APZH_ABL_B 0
+#endif
+#if APZH_ABL_T
+#define APZH_TSLICE(k)
+#else
+#define APZH_TSLICE(k) tslice(1 - par, 1 - par, std::integral_constant<int, (k)>{});
+#endif
+#if APZH_ABL_W
+#define APZH_ULOAD(k)
+#else
+#define APZH_ULOAD(k) unit_load(t, c, (k) + RING - 1, (par * 9 + (k) + RING - 1) % RING);
+#endif
+#ifndef APZH_PRIO
+#define APZH_PRIO 1
+#endif
+#if APZH_PRIO
+            // the later-dispatched half of the workgroup (waves 4..7, the SIMD partners of 0..3) loses every issue
+            // arbitration by age (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one static priority raise evens it out
+            if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+            f16x8 bfr[2];
+            auto chunk = [&](int c, auto PAR) {
+                constexpr int par = decltype(PAR)::value;
+                __syncthreads();                      // V[par] and raw[1 - par] complete; V[1 - par] and raw[par] free
+                APZH_STAMP(1)
+                const char* vp = vbase + par * T::V_BYTES;
+                // per-lane fragment offset rebuilt from an opaque copy of the lane id (kept live across the kernel it is
+                // what hipcc spills, and every scratch reload is followed by vmcnt(0): a full drain of the weight ring)
+                int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                asm volatile("" : "+v"(le));
+                const int b_hi = wpos0 * T::VPOS + (le & 31) * 16;                   // B = [Vhi | Vhi]
+                const int b_lo = b_hi + T::VTERM;                                    // B = [Vlo | Vlo]
+                bfr[0] = *reinterpret_cast<const f16x8*>(vp + b_hi);
+                bfr[1] = *reinterpret_cast<const f16x8*>(vp + b_lo);
+#define APZH_SLOT(k)                                                                                                     \
+                {                                                                                                        \
+                    constexpr int p9 = (k), slot = (par * 9 + (k)) % RING;                                               \
+                    /* the small products first: (Whi + Wlo) . Vlo, then (Whi + Wlo) . Vhi; every V fragment is re-read   \
+                       for the next position right behind the MFMA that uses it */                                        \
+                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot], bfr[1], acc[p9], 0, 0, 0);                \
+                    if (p9 + 1 < 9 && !APZH_ABL_B) bfr[1] = *reinterpret_cast<const f16x8*>(vp + b_lo + pos_off(p9 + 1)); \
+                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot], bfr[0], acc[p9], 0, 0, 0);                \
+                    if (p9 + 1 < 9 && !APZH_ABL_B) bfr[0] = *reinterpret_cast<const f16x8*>(vp + b_hi + pos_off(p9 + 1)); \
+                    if ((k) == 1 && !APZH_ABL_D) raw_dma(t, c + 2, par);                                                 \
+                    APZH_TSLICE(2 * (k))                                                                                 \
+                    APZH_TSLICE(2 * (k) + 1)                                                                             \
+                    /* unit k + RING - 1 goes into the ring slot of unit k - 1, whose MFMAs are done */                 \
+                    APZH_ULOAD(k)                                                                                        \
+                    __builtin_amdgcn_sched_barrier(0);                                                                   \
+                }
+                APZH_SLOT(0) APZH_SLOT(1) APZH_SLOT(2) APZH_SLOT(3) APZH_SLOT(4) APZH_SLOT(5) APZH_SLOT(6) APZH_SLOT(7) APZH_SLOT(8)
+#undef APZH_SLOT
+                APZH_STAMP(2)
+            };
+            for (int c = 0; c < T::NCHUNK; c += 2) {
+                chunk(c, std::integral_constant<int, 0>{});
+                chunk(c + 1, std::integral_constant<int, 1>{});
+            }
+
+            // ---- epilogue: four steps of 16 output channels (32-channel half cs, quarter q2); the waves of half cs hold
+            // the step's accumulators.  Layout of the 32 x 32 tile: lane (col = lane & 31, hh = lane >> 5), register v:
+            // channel (v & 3) + 8 (v >> 2) + 4 hh.
+            const int cosel = lane >> 5;               // gather role: channel 2 wave + cosel of the step's 16, column lane & 31
+            const int col = lane & 31, gbd = col >> 4, gtile = col & 15;
+            const int gty = gtile >> 2, gtx = gtile & 3;
+            float* sw = stg + wave * (4 * T::SPLANE);
+            const int s_lin = (lane >> 2) * T::SROW + (lane & 3) * 4;
+            const unsigned ep_vo = lane < 60 ? lane * 16 : 0x80000000u;
+            auto ep_step = [&](auto S_) {
+                constexpr int s = decltype(S_)::value;
+                constexpr int cs = s >> 1, q2 = s & 1;
+                const int co_base = (2 * h + cs) * 32 + 16 * q2;         // first output channel of the step
+                __syncthreads();                       // MFMAs over V done (s = 0) / M and staging of the previous step consumed
+                APZH_STAMP(1)
+                if (s == 0 && t + 1 < nitems) {        // the raw tiles are free: the next item's first two chunks
+                    raw_dma(t + 1, 0, 0);
+                    raw_dma(t + 1, 1, 1);
+                }
+                // residual planes of this wave (2 channels x 2 boards), requested before the accumulators move
+                f32x4 rs[4];
+                if (RESID) {
+#pragma unroll
+                    for (int pl = 0; pl < 4; pl++) {
+                        const int bdp = bd0 + (pl & 1);
+                        const int bd = bdp < n ? bdp : n - 1;
+                        rs[pl] = bload(r_res, ep_vo, (unsigned)(bd * T::C + co_base + 2 * wave + (pl >> 1)) * plane_b);
+                    }
+                }
+                if (cc == cs) {
+                    float* mw = mq + wpos0 * 512 + (4 * hh) * 32 + r31;
+#pragma unroll
+                    for (int p9 = 0; p9 < 9; p9++)
+#pragma unroll
+                        for (int ee = 0; ee < 8; ee++)
+                            mw[(6 * (p9 / 3) + p9 % 3) * 512 + ((ee & 3) + 8 * (ee >> 2)) * 32] = acc[p9][8 * q2 + ee];
+                }
+                if (RESID) {
+#pragma unroll
+                    for (int pl = 0; pl < 4; pl++) *reinterpret_cast<f32x4*>(sw + pl * T::SPLANE + s_lin) = rs[pl];
+                }
+                __syncthreads();                       // M complete
+                APZH_STAMP(1)
+                {
+                    const int co16 = 2 * wave + cosel;
+                    const float* mp = mq + co16 * 32 + col;
+                    float hrow[6][4];                   // the k-direction transform of every row
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        float m[6];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) m[k] = mp[(6 * i + k) * 512];
+                        const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                        hrow[i][0] = (m[0] + s12) + s34;
+                        hrow[i][1] = __builtin_fmaf(2.f, d34, d12);
+                        hrow[i][2] = __builtin_fmaf(4.f, s34, s12);
+                        hrow[i][3] = __builtin_fmaf(8.f, d34, d12) + m[5];
+                    }
+                    const float bv = bias[co_base + co16];
+                    const float is = bias[128 + co_base + co16];         // 1 / S of the channel (a power of two)
+                    float* sp = sw + (cosel * 2 + gbd) * T::SPLANE + (4 * gty) * T::SROW + 4 * gtx;
+                    f32x4 y[4];
+#pragma unroll
+                    for (int ee = 0; ee < 4; ee++) {
+                        const float s12 = hrow[1][ee] + hrow[2][ee], d12 = hrow[1][ee] - hrow[2][ee];
+                        const float s34 = hrow[3][ee] + hrow[4][ee], d34 = hrow[3][ee] - hrow[4][ee];
+                        y[0][ee] = (hrow[0][ee] + s12) + s34;
+                        y[1][ee] = __builtin_fmaf(2.f, d34, d12);
+                        y[2][ee] = __builtin_fmaf(4.f, s34, s12);
+                        y[3][ee] = __builtin_fmaf(8.f, d34, d12) + hrow[5][ee];
+                    }
+                    float chk = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        f32x4 v;
+#pragma unroll
+                        for (int ee = 0; ee < 4; ee++) v[ee] = __builtin_fmaf(y[a][ee], is, bv);
+                        if (RESID) v += *reinterpret_cast<const f32x4*>(sp + a * T::SROW);   // (wave-private: written above by this wave)
+                        chk += (v[0] + v[1]) + (v[2] + v[3]);   // an overflow of the fp16 split shows as +-inf / NaN here
+#pragma unroll
+                        for (int ee = 0; ee < 4; ee++) v[ee] = RELU ? fmaxf(v[ee], 0.f) : v[ee];
+                        if (gtx == 3) v[3] = 0.f;      // column 15 is the halo column of the rows16 layout
+                        *reinterpret_cast<f32x4*>(sp + a * T::SROW) = v;   // (same lane, same addresses as the residual it read)
+                    }
+                    nonfinite |= ((chk - chk) != 0.f) ? 1u : 0u;         // 0 for every finite sum; NaN != 0 is true
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int pl = 0; pl < 4; pl++) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(sw + pl * T::SPLANE + s_lin);
+                    const unsigned vo = ((pl & 1) == 0 || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch
+                    bstore(r_out, vo, (unsigned)((bd0 + (pl & 1)) * T::C + co_base + 2 * wave + (pl >> 1)) * plane_b, pv);
+                }
+                APZH_STAMP(3)
+            };
+            ep_step(std::integral_constant<int, 0>{});
+            ep_step(std::integral_constant<int, 1>{});
+            ep_step(std::integral_constant<int, 2>{});
+            ep_step(std::integral_constant<int, 3>{});
+            // (the next item's prologue starts with a barrier: M / staging are consumed before its transform writes V)
+        }
+    };
+    if (((wave >> 1) & 1) == 0)
+        run(std::integral_constant<int, 0>{});
+    else
+        run(std::integral_constant<int, 1>{});
+    if (nonfinite && flag) atomicOr(flag, 1u);
+#ifdef APZ_WINO3H_STAMPS
+    st_acc[7] = __builtin_readcyclecounter() - st_t0;
+    if (lane == 0 && blockIdx.x < 4)
+        for (int i = 0; i < 8; i++) apz_wino3h_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_acc[i];
+#endif
+}
+
+}  // namespace apz
