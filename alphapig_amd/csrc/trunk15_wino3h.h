@@ -109,7 +109,7 @@ inline void wino3h_pack_host(F u_of, std::vector<uint16_t>& out, float* inv_scal
 }
 
 #ifdef APZ_WINO3H_STAMPS
-__device__ unsigned long long apz_wino3h_stamps[4 * 8 * 8];   // [workgroup 4][wave 8][phase 8]
+__device__ unsigned long long apz_wino3h_stamps[4 * 8 * 12];   // [workgroup 4][wave 8][phase 12]
 #endif
 
 #ifndef APZH_RING
@@ -122,10 +122,13 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                                                              float* __restrict__ out, int n, unsigned* __restrict__ flag) {
     using T = Wino3H;
 #ifdef APZ_WINO3H_STAMPS
-    // phases: 0 item prologue, 1 barrier waits, 2 chunk bodies, 3 epilogue, 7 total
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // phases: 0 item prologue (transform), 1 chunk barrier waits, 2 chunk bodies, 3 epilogue work, 4 epilogue barrier waits,
+    // 5 item start (wait for the first planes + barrier), 6 = s_memrealtime ticks (100 MHz) of the whole wave, 7 total;
+    // epilogue detail: 4 = waits at a step's first barrier, 8 = M write + residual, 10 = waits at the second barrier, 9 = gather +
+    // output transform, 3 = staging + stores
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t = __builtin_readcyclecounter();
-    const unsigned long long st_t0 = st_t;
+    const unsigned long long st_t0 = st_t, st_r0 = __builtin_amdgcn_s_memrealtime();
 #define APZH_STAMP(ph_)                                               \
     {                                                                 \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -211,10 +214,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
         if (c >= T::NCHUNK) { c -= T::NCHUNK; t += 1; }
         if (t >= nitems) { t = nitems - 1; c = T::NCHUNK - 1; p9 = 8; }
         const int cog = 2 * item_half(t) + cc;
+#if defined(APZH_ABL_W) && APZH_ABL_W == 2   /* measurement build: every weight load reads the same (L1-resident) unit */
+        const unsigned so = (unsigned)(cog * 4 + blk) * T::UNIT + 0u * (unsigned)(c + p9);
+#else
         const unsigned so = (unsigned)(((cog * 4 + blk) * T::NCHUNK + c) * 9 + p9) * T::UNIT;
+#endif
         af[slot] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_u, a_vo, so, 0));
     };
 
+    auto af_keep = [&](int s_) { asm volatile("" ::"v"(af[s_])); };   // (measurement builds)
+    (void)af_keep;
     unsigned nonfinite = 0;                           // any pre-ReLU output of this thread that is not a finite number
 
     // Everything that depends on the row half of the transform role is instantiated twice (wave-uniform branch below)
@@ -335,6 +344,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
             // ---- item prologue: raw(0), raw(1) have been requested; V[0] = transform(raw(0))
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            APZH_STAMP(5)
             transform(0, 0);
             f32x16h acc[9];
 #pragma unroll
@@ -359,12 +369,39 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
 #ifndef APZH_ABL_B
 #define APZH_ABL_B 0
 #endif
+#ifndef APZH_ABL_M
+#define APZH_ABL_M 0      /* no MFMAs in the chunk loop */
+#endif
+#ifndef APZH_ABL_S
+#define APZH_ABL_S 0      /* no barrier at the top of a chunk (races: timing only) */
+#endif
+#if APZH_ABL_M
+#define APZH_MFMA_NONE(a_, b_, c_) asm volatile("" ::"v"(a_), "v"(b_))
+#endif
+#if APZH_ABL_W == 3           /* the weight ring keeps streaming, the MFMAs read one fixed unit: no per-slot wait for a load */
+#define APZH_AF(slot_) af_fixed
+#define APZH_AF_KEEP(slot_) af_keep(slot_);
+#else
+#define APZH_AF(slot_) af[slot_]
+#define APZH_AF_KEEP(slot_)
+#endif
+#define APZH_MFMA_REAL(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#if APZH_ABL_M == 1
+#define APZH_MFMA_LO APZH_MFMA_NONE
+#define APZH_MFMA_HI APZH_MFMA_NONE
+#elif APZH_ABL_M == 2         /* one MFMA per slot */
+#define APZH_MFMA_LO APZH_MFMA_NONE
+#define APZH_MFMA_HI APZH_MFMA_REAL
+#else
+#define APZH_MFMA_LO APZH_MFMA_REAL
+#define APZH_MFMA_HI APZH_MFMA_REAL
+#endif
 #if APZH_ABL_T
 #define APZH_TSLICE(k)
 #else
 #define APZH_TSLICE(k) tslice(1 - par, 1 - par, std::integral_constant<int, (k)>{});
 #endif
-#if APZH_ABL_W
+#if APZH_ABL_W == 1
 #define APZH_ULOAD(k)
 #else
 #define APZH_ULOAD(k) unit_load(t, c, (k) + RING - 1, (par * 9 + (k) + RING - 1) % RING);
@@ -378,9 +415,13 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
             if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
             f16x8 bfr[2];
+#if APZH_ABL_W == 3
+            f16x8 af_fixed = af[0];
+            asm volatile("" : "+v"(af_fixed));
+#endif
             auto chunk = [&](int c, auto PAR) {
                 constexpr int par = decltype(PAR)::value;
-                __syncthreads();                      // V[par] and raw[1 - par] complete; V[1 - par] and raw[par] free
+                if (!APZH_ABL_S) __syncthreads();     // V[par] and raw[1 - par] complete; V[1 - par] and raw[par] free
                 APZH_STAMP(1)
                 const char* vp = vbase + par * T::V_BYTES;
                 // per-lane fragment offset rebuilt from an opaque copy of the lane id (kept live across the kernel it is
@@ -396,9 +437,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                     constexpr int p9 = (k), slot = (par * 9 + (k)) % RING;                                               \
                     /* the small products first: (Whi + Wlo) . Vlo, then (Whi + Wlo) . Vhi; every V fragment is re-read   \
                        for the next position right behind the MFMA that uses it */                                        \
-                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot], bfr[1], acc[p9], 0, 0, 0);                \
+                    APZH_MFMA_LO(APZH_AF(slot), bfr[1], acc[p9]);                                                        \
                     if (p9 + 1 < 9 && !APZH_ABL_B) bfr[1] = *reinterpret_cast<const f16x8*>(vp + b_lo + pos_off(p9 + 1)); \
-                    acc[p9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot], bfr[0], acc[p9], 0, 0, 0);                \
+                    APZH_MFMA_HI(APZH_AF(slot), bfr[0], acc[p9]);                                                        \
                     if (p9 + 1 < 9 && !APZH_ABL_B) bfr[0] = *reinterpret_cast<const f16x8*>(vp + b_hi + pos_off(p9 + 1)); \
                     if ((k) == 1 && !APZH_ABL_D) raw_dma(t, c + 2, par);                                                 \
                     APZH_TSLICE(2 * (k))                                                                                 \
@@ -409,6 +450,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 }
                 APZH_SLOT(0) APZH_SLOT(1) APZH_SLOT(2) APZH_SLOT(3) APZH_SLOT(4) APZH_SLOT(5) APZH_SLOT(6) APZH_SLOT(7) APZH_SLOT(8)
 #undef APZH_SLOT
+                APZH_AF_KEEP(0) APZH_AF_KEEP(1) APZH_AF_KEEP(2) APZH_AF_KEEP(3) APZH_AF_KEEP(4) APZH_AF_KEEP(5)
                 APZH_STAMP(2)
             };
             for (int c = 0; c < T::NCHUNK; c += 2) {
@@ -430,7 +472,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 constexpr int cs = s >> 1, q2 = s & 1;
                 const int co_base = (2 * h + cs) * 32 + 16 * q2;         // first output channel of the step
                 __syncthreads();                       // MFMAs over V done (s = 0) / M and staging of the previous step consumed
-                APZH_STAMP(1)
+                APZH_STAMP(4)
                 if (s == 0 && t + 1 < nitems) {        // the raw tiles are free: the next item's first two chunks
                     raw_dma(t + 1, 0, 0);
                     raw_dma(t + 1, 1, 1);
@@ -457,8 +499,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
 #pragma unroll
                     for (int pl = 0; pl < 4; pl++) *reinterpret_cast<f32x4*>(sw + pl * T::SPLANE + s_lin) = rs[pl];
                 }
+                APZH_STAMP(8)
                 __syncthreads();                       // M complete
-                APZH_STAMP(1)
+                APZH_STAMP(10)
                 {
                     const int co16 = 2 * wave + cosel;
                     const float* mp = mq + co16 * 32 + col;
@@ -502,6 +545,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                     }
                     nonfinite |= ((chk - chk) != 0.f) ? 1u : 0u;         // 0 for every finite sum; NaN != 0 is true
                 }
+                APZH_STAMP(9)
                 wave_lds_fence();
 #pragma unroll
                 for (int pl = 0; pl < 4; pl++) {
@@ -525,8 +569,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
     if (nonfinite && flag) atomicOr(flag, 1u);
 #ifdef APZ_WINO3H_STAMPS
     st_acc[7] = __builtin_readcyclecounter() - st_t0;
+    st_acc[6] = __builtin_amdgcn_s_memrealtime() - st_r0;
     if (lane == 0 && blockIdx.x < 4)
-        for (int i = 0; i < 8; i++) apz_wino3h_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_acc[i];
+        for (int i = 0; i < 12; i++) apz_wino3h_stamps[(blockIdx.x * 8 + wave) * 12 + i] = st_acc[i];
 #endif
 }
 

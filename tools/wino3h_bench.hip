@@ -253,13 +253,17 @@ int main(int argc, char** argv) {
     }
 #ifdef APZ_WINO3H_STAMPS
     {
-        unsigned long long st[4 * 8 * 8];
-        launch(0, 1, 256, 512, out[0]);
+        unsigned long long st[4 * 8 * 12];
+        for (int resid = 1; resid >= 0; resid--) {
+        printf("stamps of one launch, 512 boards, resid=%d\n", resid);
+        for (int it = 0; it < 4; it++) launch(0, resid, 256, 512, out[0]);
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(apz::apz_wino3h_stamps), sizeof st));
         for (int w = 0; w < 8; w++)
-            printf("stamps wg0 wave %d: prologue %llu barriers %llu chunks %llu epilogue %llu total %llu cycles\n", w, st[w * 8 + 0], st[w * 8 + 1],
-                   st[w * 8 + 2], st[w * 8 + 3], st[w * 8 + 7]);
+            printf("stamps wg0 wave %d: start-wait %llu prologue %llu chunk-barriers %llu chunks %llu | epilogue: barrier1 %llu M-write+resid %llu barrier2 %llu gather+transform %llu staging+stores %llu | total %llu cycles in %.2f us (%.2f GHz)\n", w,
+                   st[w * 12 + 5], st[w * 12 + 0], st[w * 12 + 1], st[w * 12 + 2], st[w * 12 + 4], st[w * 12 + 8], st[w * 12 + 10], st[w * 12 + 9], st[w * 12 + 3],
+                   st[w * 12 + 7], st[w * 12 + 6] * 0.01, st[w * 12 + 7] / (st[w * 12 + 6] * 10.0));
+        }
     }
 #endif
     printf("RESULT %s\n", bad ? "MISMATCH" : "OK");
