@@ -23,10 +23,9 @@
 //         A = [Whi | Wlo] (lanes 0-31 hold k = 0-7, lanes 32-63 k = 8-15), B = [Vt | Vt] for t = lo, then t = hi:
 //     two MFMAs per (position, 32 output channels, 8 input channels) instead of three, ONE 16-byte weight load per lane
 //     and unit (1 KB per wave, fully coalesced; 4 bytes per weight as in the fp32 kernel), two V fragments per position.
-//   * The split: hi = v_cvt_pk_f16_f32 of (my value, my pair partner's), remainder = v_fma_mix_f32 (exact), lo =
-//     v_cvt_pk_f16_f32 of the remainders: 4 vector instructions per position and channel pair (bf16 x 3: 11).  Odd lanes
-//     pack their own (odd) channel into the low half: for positions k = 3..5 of a row the two channels of a pair are
-//     swapped in V -- and in the packed weights (upk_offset), so the contraction pairs them up again.
+//   * The split: hi = v_cvt_pk_f16_f32 of (even channel's value, odd channel's), lo = v_fma_mixlo / mixhi_f16 of the exact
+//     remainders: 3 vector instructions per position and channel pair (bf16 x 3: 11); the two channels of a pair meet by
+//     ONE v_permlane16_swap_b32 per value pair (DPP: two selects and a move); the transform itself on column pairs (v_pk).
 //
 // Layouts.  in / resid / out: rows16 [n][128][15][16] (col 15 == 0).  raw (LDS): as Wino3B.  V (LDS): [pos 36][term 2]
 // [col 32][8 ch] fp16, col = board * 16 + tile: a B fragment is ONE conflict-free ds_read_b128 (both lane halves read the
@@ -69,7 +68,7 @@ struct Wino3H {
     __host__ __device__ static size_t upk_offset(int co, int ci, int pos, int term) {
         const int i = pos / 6, k = pos % 6, ri = i / 3, ki = k / 3, p9 = 3 * (i % 3) + (k % 3);
         const int cog = co >> 5, r = co & 31, chunk = ci >> 3, w = 2 * ri + ki;
-        const int ch = (ci & 7) ^ (k >= 3 ? 1 : 0);                    // positions packed by the odd lanes: pair swapped
+        const int ch = ci & 7;
         return ((((size_t)(cog * 4 + w) * NCHUNK + chunk) * 9 + p9) * 2 + term) * VTERM + r * 16 + ch * 2;
     }
     // the power of two that puts m = max |U| of an output channel into [2^13, 2^14) (m == 0: 1)
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
 
     // weight stream: unit index of this wave = (item t * 16 + chunk c) * 9 + p9
     static constexpr int RING = APZH_RING;
-    static_assert(RING == 6 || RING == 9, "ring slots must tile two chunks");
+    static_assert(RING == 6 || RING == 9 || RING == 18, "ring slots must tile two chunks");
     f16x8 af[RING];
     auto unit_load = [&](int t, int c, int p9, int slot) {
         // (c, p9) may run past the end of the item: carry into the next item; past the last item: reload the last unit
@@ -229,95 +228,108 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
     // Everything that depends on the row half of the transform role is instantiated twice (wave-uniform branch below)
     auto run = [&](auto PH) {
         constexpr int ph = decltype(PH)::value;
-        // ---- transform role: board tb, row half ph, channels 4 ch4 .. 4 ch4 + 3.  lane -> (tile row tty, tile column
-        // ttx, channel); bit 0 = channel parity e: the two channels of a pair are DPP neighbours (trunk15_wino3b.h).
+        // ---- transform role: board tb, row half ph, channels 4 ch4 .. 4 ch4 + 3.  lane -> (tile column ttx = bits 0-1, tile
+        // row tty = bits 2 and 5, pair cpl = bit 3, channel parity e = bit 4): the two channels of a pair sit 16 lanes apart
+        // (v_permlane16_swap_b32 exchanges them, below), and every 16-lane group a ds_read_b128 is served in ({0-3,12-15,
+        // 20-27}, {4-11,16-19,28-31}, the same + 32) holds all sixteen (channel of four, ttx): with the plane stride of 272
+        // floats (68 bank quads = 4 mod 16; a tile row is 16 quads) its reads fall on sixteen different bank quads.
         const int tb = wave & 1, ch4 = wave >> 2;
-        const int e = lane & 1, run4 = (lane >> 2) & 7;
-        const int ttx = 2 * ((run4 >> 1) & 1) + ((lane >> 1) & 1), cpl = run4 >> 2;
-        const int tty = 2 * (lane >> 5) + 1 - ((0x69 >> run4) & 1);
+        const int ttx = lane & 3, cpl = (lane >> 3) & 1, e = (lane >> 4) & 1;
+        const int tty = 2 * (lane >> 5) + ((lane >> 2) & 1);
         const int tile = 4 * tty + ttx, chl = 4 * ch4 + 2 * cpl + e;          // channel of the chunk (0..7)
         const int tr_off = T::RFRONT + (tb * 8 + chl) * T::RPS + (4 * tty - 1 + ph) * T::RROW + 4 * ttx;
         const unsigned col16_mask = ttx == 3 ? 0u : 0xffffffffu;   // column 16 does not exist: the word there is column 0 of the next row
-        // bytes: column tb * 16 + tile, dword = channel pair; even lanes pack positions k = 0..2 of a row, odd lanes 3..5
+        // bytes: column tb * 16 + tile, dword = channel pair (low half: the even channel); lanes of the even channel pack
+        // positions k = 0..2 of a row, lanes of the odd channel k = 3..5
         const int tv_off = tb * 256 + tile * 16 + (2 * ch4 + cpl) * 4 + e * 3 * T::VPOS;
-        float xr[5][4];                                // five patch rows of the channel: four columns at a time
-        float tt[3][6];                                // row-pass results (rows 3 ph .. 3 ph + 2), columns -1 .. 4
+        // All of the transform runs on column PAIRS (v_pk_* instructions: vector instruction slots, not flops, are what the
+        // chunk loop is short of -- profiles/r06_wino3h.md): pair 0 = columns (0, 1), 1 = (2, 3), 2 = the halo (-1, 4).
+        f32x2 xr[5][2];                                // five patch rows: the two centre pairs
+        f32x2 tt[3][3];                                // row-pass results (rows 3 ph .. 3 ph + 2) of the three column pairs
         float oo[6];
-        auto row_pass = [&](const float* rp, auto PART) {
-            constexpr int part = decltype(PART)::value;
-            constexpr int nc = part == 0 ? 4 : 2;
+        // the patch rows come out of LDS one MFMA slot before the row pass uses them (slice 0 only issues the reads: an
+        // in-order wave that waits for an LDS round trip right behind its reads cannot issue its next MFMAs meanwhile)
+        float xhl[5], xhr[5];                          // the halo columns (-1 and 4) of the five patch rows
+        auto row_load = [&](const float* rp) {
 #pragma unroll
             for (int i = 0; i < 5; i++) {
-                if (part == 0) {
-                    const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
-                    xr[i][0] = c03[0]; xr[i][1] = c03[1]; xr[i][2] = c03[2]; xr[i][3] = c03[3];
-                } else {
-                    xr[i][0] = rp[i * T::RROW - 1];
-                    xr[i][1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rp[i * T::RROW + 4]) & col16_mask);   // (no branch)
-                }
+                const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
+                xr[i][0] = f32x2{c03[0], c03[1]};
+                xr[i][1] = f32x2{c03[2], c03[3]};
+                xhl[i] = rp[i * T::RROW - 1];
+                xhr[i] = rp[i * T::RROW + 4];
             }
+        };
+        auto row_pass = [&]() {
+            f32x2 xh[5];
 #pragma unroll
-            for (int k = 0; k < nc; k++) {
-                const int kc = part == 0 ? k + 1 : 5 * k;      // column index in tt (0 = column -1, 5 = column 4)
+            for (int i = 0; i < 5; i++)
+                xh[i] = f32x2{xhl[i], __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xhr[i]) & col16_mask)};   // (no branch)
+#pragma unroll
+            for (int kc = 0; kc < 3; kc++) {
+                f32x2 x[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) x[i] = kc < 2 ? xr[i][kc] : xh[i];
                 if (ph == 0) {                         // x = patch rows 0..4: y0 = 4x0 - 5x2 + x4, y1/y2 = (x4 - 4x2) +- (x3 - 4x1)
-                    const float a = __builtin_fmaf(-4.f, xr[2][k], xr[4][k]), b = __builtin_fmaf(-4.f, xr[1][k], xr[3][k]);
-                    tt[0][kc] = __builtin_fmaf(4.f, xr[0][k], __builtin_fmaf(-5.f, xr[2][k], xr[4][k]));
+                    const f32x2 a = fma2(-4.f, x[2], x[4]), b = fma2(-4.f, x[1], x[3]);
+                    tt[0][kc] = fma2(4.f, x[0], fma2(-5.f, x[2], x[4]));
                     tt[1][kc] = a + b;
                     tt[2][kc] = a - b;
                 } else {                               // z = patch rows 1..5: y3/y4 = (z3 - z1) +- 2(z2 - z0), y5 = 4z0 - 5z2 + z4
-                    const float c = xr[3][k] - xr[1][k], d = xr[2][k] - xr[0][k];
-                    tt[0][kc] = __builtin_fmaf(2.f, d, c);
-                    tt[1][kc] = __builtin_fmaf(-2.f, d, c);
-                    tt[2][kc] = __builtin_fmaf(4.f, xr[0][k], __builtin_fmaf(-5.f, xr[2][k], xr[4][k]));
+                    const f32x2 c = x[3] - x[1], d = x[2] - x[0];
+                    tt[0][kc] = fma2(2.f, d, c);
+                    tt[1][kc] = fma2(-2.f, d, c);
+                    tt[2][kc] = fma2(4.f, x[0], fma2(-5.f, x[2], x[4]));
                 }
             }
         };
-        auto col_pass = [&](const float* v, float* o) {   // B^T over the columns of one row
-            const float a = __builtin_fmaf(-4.f, v[2], v[4]), b = __builtin_fmaf(-4.f, v[1], v[3]);
-            const float c = v[4] - v[2], d = v[3] - v[1];
-            o[0] = __builtin_fmaf(4.f, v[0], __builtin_fmaf(-5.f, v[2], v[4]));
-            o[1] = a + b;
-            o[2] = a - b;
-            o[3] = __builtin_fmaf(2.f, d, c);
-            o[4] = __builtin_fmaf(-2.f, d, c);
-            o[5] = __builtin_fmaf(4.f, v[1], __builtin_fmaf(-5.f, v[3], v[5]));
+        // B^T over the columns of one row: v = (v1, v2), (v3, v4), (v0, v5) -> o[0..5]
+        auto col_pass = [&](const f32x2* t, float* o) {
+            const f32x2 ab = fma2(-4.f, t[0], t[1]);   // (b, a) = (v3 - 4 v1, v4 - 4 v2)
+            const f32x2 dc = t[1] - t[0];              // (d, c) = (v3 - v1, v4 - v2)
+            o[0] = __builtin_fmaf(4.f, t[2][0], __builtin_fmaf(-5.f, t[0][1], t[1][1]));
+            o[3] = __builtin_fmaf(2.f, dc[0], dc[1]);
+            o[1] = ab[1] + ab[0];
+            o[4] = __builtin_fmaf(-2.f, dc[0], dc[1]);
+            o[2] = ab[1] - ab[0];
+            o[5] = __builtin_fmaf(4.f, t[0][0], __builtin_fmaf(-5.f, t[1][0], t[2][1]));
         };
-        // my value and my pair partner's value of one position -> two dwords of fp16 pairs (low half: mine): hi = both
-        // values rounded to fp16, lo = the remainders (exact in fp32) rounded to fp16
-        auto emit = [&](char* vp, float mine, float theirs) {
+        // The six values of a row: lanes of the even channel keep o[0..2] and hand o[3..5] to their pair partner (16 lanes
+        // up), lanes of the odd channel the other way round.  v_permlane16_swap_b32 a, b swaps a's odd 16-lane rows with b's
+        // even ones: afterwards (o[k], o[k + 3]) is (even channel's value, odd channel's value) of position k in the even
+        // channel's lanes and of position k + 3 in the odd channel's -- one instruction per value pair where DPP needed two
+        // selects and a move.  (gfx950 wants two wait states between a vector write of an operand and the swap: s_nop 1.)
+        auto exchange = [&](float* o) {
+            asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %3\n\tv_permlane16_swap_b32 %1, %4\n\tv_permlane16_swap_b32 %2, %5"
+                : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]));
+        };
+        // (even channel's value, odd channel's value) of one position -> two dwords of fp16 pairs: hi = both values rounded
+        // to fp16, lo = the remainders (exact in fp32: v_fma_mix) rounded to fp16
+        auto emit = [&](char* vp, float ev, float od) {
             typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
-            const f16x2_ h2 = {(_Float16)mine, (_Float16)theirs};            // v_cvt_pk_f16_f32
+            const f16x2_ h2 = {(_Float16)ev, (_Float16)od};                  // v_cvt_pk_f16_f32
             const unsigned hu = __builtin_bit_cast(unsigned, h2);
-            float rm, rt;
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rm) : "v"(hu), "v"(mine));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rt) : "v"(hu), "v"(theirs));
-            const f16x2_ l2 = {(_Float16)rm, (_Float16)rt};
+            unsigned lu;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "v"(ev));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "v"(od));
             *reinterpret_cast<unsigned*>(vp) = hu;
-            *reinterpret_cast<unsigned*>(vp + T::VTERM) = __builtin_bit_cast(unsigned, l2);
+            *reinterpret_cast<unsigned*>(vp + T::VTERM) = lu;
         };
         // The transform of one chunk (raw[rpar] -> V[vpar], this thread's channel, rows 3 ph .. 3 ph + 2) in 18 slices, two
         // per MFMA slot of a chunk body
-        float mine3[3], theirs3[3];
         auto tslice = [&](int rpar, int vpar, auto KK) {
             constexpr int K = decltype(KK)::value;
             const float* rp = rawb + rpar * T::RAW_FLOATS + tr_off;
             char* vp = vbase + vpar * T::V_BYTES + tv_off;
-            if constexpr (K == 0) row_pass(rp, std::integral_constant<int, 0>{});
-            else if constexpr (K == 1) row_pass(rp, std::integral_constant<int, 1>{});
+            if constexpr (K == 0) row_load(rp);
+            else if constexpr (K == 2) row_pass();
             else if constexpr (K >= 3 && K < 18) {
                 constexpr int ii = (K - 3) / 5, part = (K - 3) % 5;
                 if constexpr (part == 0) col_pass(tt[ii], oo);
-                else if constexpr (part == 1) {
-                    // the three values I pack myself and the three my partner packs; the partner's come over by DPP
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        mine3[k] = e ? oo[k + 3] : oo[k];
-                        const float send = e ? oo[k] : oo[k + 3];
-                        theirs3[k] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-                    }
-                } else {
+                else if constexpr (part == 1) exchange(oo);
+                else {
                     constexpr int k = part - 2;
-                    emit(vp + ((3 * ph + ii) * 6 + k) * T::VPOS, mine3[k], theirs3[k]);
+                    emit(vp + ((3 * ph + ii) * 6 + k) * T::VPOS, oo[k], oo[k + 3]);
                 }
             }
         };
@@ -396,8 +408,10 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
 #define APZH_MFMA_LO APZH_MFMA_REAL
 #define APZH_MFMA_HI APZH_MFMA_REAL
 #endif
-#if APZH_ABL_T
+#if APZH_ABL_T == 1
 #define APZH_TSLICE(k)
+#elif APZH_ABL_T == 2       /* the transform's work twice (same results): is there slack for vector instructions? */
+#define APZH_TSLICE(k) tslice(1 - par, 1 - par, std::integral_constant<int, (k)>{}); tslice(1 - par, 1 - par, std::integral_constant<int, (k)>{});
 #else
 #define APZH_TSLICE(k) tslice(1 - par, 1 - par, std::integral_constant<int, (k)>{});
 #endif
@@ -458,42 +472,44 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 chunk(c + 1, std::integral_constant<int, 1>{});
             }
 
-            // ---- epilogue: four steps of 16 output channels (32-channel half cs, quarter q2); the waves of half cs hold
-            // the step's accumulators.  Layout of the 32 x 32 tile: lane (col = lane & 31, hh = lane >> 5), register v:
-            // channel (v & 3) + 8 (v >> 2) + 4 hh.
-            const int cosel = lane >> 5;               // gather role: channel 2 wave + cosel of the step's 16, column lane & 31
+            // ---- epilogue: four steps of 16 output channels = channels 8 s .. 8 s + 7 of BOTH 32-channel halves, so that
+            // all eight waves move accumulators in every step (a step of one half left four waves idle while the other four
+            // wrote 72 values each: profiles/r06_wino3h.md).  Layout of the 32 x 32 tile: lane (col = lane & 31, hh =
+            // lane >> 5), register v: channel (v & 3) + 8 (v >> 2) + 4 hh -- registers 4 s .. 4 s + 3 are channels 8 s +
+            // (0..3) + 4 hh.  M row (of 16) = 8 cc + channel - 8 s.
+            const int cosel = lane >> 5;               // gather role: M row 2 wave + cosel of the step's 16, column lane & 31
             const int col = lane & 31, gbd = col >> 4, gtile = col & 15;
             const int gty = gtile >> 2, gtx = gtile & 3;
             float* sw = stg + wave * (4 * T::SPLANE);
             const int s_lin = (lane >> 2) * T::SROW + (lane & 3) * 4;
             const unsigned ep_vo = lane < 60 ? lane * 16 : 0x80000000u;
+            // output channel of M row `row` in step s
+            auto row_chan = [&](int s, int row) { return (2 * h + (row >> 3)) * 32 + 8 * s + (row & 7); };
+            // residual planes of this wave (its 2 M rows x 2 boards), requested a step ahead of their use
+            f32x4 rs[4];
+            auto resid_request = [&](int s) {
+#pragma unroll
+                for (int pl = 0; pl < 4; pl++) {
+                    const int bdp = bd0 + (pl & 1);
+                    const int bd = bdp < n ? bdp : n - 1;
+                    rs[pl] = bload(r_res, ep_vo, (unsigned)(bd * T::C + row_chan(s, 2 * wave + (pl >> 1))) * plane_b);
+                }
+            };
+            if (RESID) resid_request(0);
             auto ep_step = [&](auto S_) {
                 constexpr int s = decltype(S_)::value;
-                constexpr int cs = s >> 1, q2 = s & 1;
-                const int co_base = (2 * h + cs) * 32 + 16 * q2;         // first output channel of the step
                 __syncthreads();                       // MFMAs over V done (s = 0) / M and staging of the previous step consumed
                 APZH_STAMP(4)
                 if (s == 0 && t + 1 < nitems) {        // the raw tiles are free: the next item's first two chunks
                     raw_dma(t + 1, 0, 0);
                     raw_dma(t + 1, 1, 1);
                 }
-                // residual planes of this wave (2 channels x 2 boards), requested before the accumulators move
-                f32x4 rs[4];
-                if (RESID) {
-#pragma unroll
-                    for (int pl = 0; pl < 4; pl++) {
-                        const int bdp = bd0 + (pl & 1);
-                        const int bd = bdp < n ? bdp : n - 1;
-                        rs[pl] = bload(r_res, ep_vo, (unsigned)(bd * T::C + co_base + 2 * wave + (pl >> 1)) * plane_b);
-                    }
-                }
-                if (cc == cs) {
-                    float* mw = mq + wpos0 * 512 + (4 * hh) * 32 + r31;
+                {
+                    float* mw = mq + wpos0 * 512 + (8 * cc + 4 * hh) * 32 + r31;
 #pragma unroll
                     for (int p9 = 0; p9 < 9; p9++)
 #pragma unroll
-                        for (int ee = 0; ee < 8; ee++)
-                            mw[(6 * (p9 / 3) + p9 % 3) * 512 + ((ee & 3) + 8 * (ee >> 2)) * 32] = acc[p9][8 * q2 + ee];
+                        for (int e4 = 0; e4 < 4; e4++) mw[(6 * (p9 / 3) + p9 % 3) * 512 + e4 * 32] = acc[p9][4 * s + e4];
                 }
                 if (RESID) {
 #pragma unroll
@@ -517,8 +533,12 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                         hrow[i][2] = __builtin_fmaf(4.f, s34, s12);
                         hrow[i][3] = __builtin_fmaf(8.f, d34, d12) + m[5];
                     }
-                    const float bv = bias[co_base + co16];
-                    const float is = bias[128 + co_base + co16];         // 1 / S of the channel (a power of two)
+                    // the next step's residual planes: behind the gather (their registers are free now), in front of this
+                    // step's stores (vmcnt counts in issue order: the wait for them must not include those stores)
+                    if (RESID && s + 1 < 4) resid_request(s + 1);
+                    const int ch = row_chan(s, co16);
+                    const float bv = bias[ch];
+                    const float is = bias[128 + ch];                     // 1 / S of the channel (a power of two)
                     float* sp = sw + (cosel * 2 + gbd) * T::SPLANE + (4 * gty) * T::SROW + 4 * gtx;
                     f32x4 y[4];
 #pragma unroll
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 for (int pl = 0; pl < 4; pl++) {
                     const f32x4 pv = *reinterpret_cast<const f32x4*>(sw + pl * T::SPLANE + s_lin);
                     const unsigned vo = ((pl & 1) == 0 || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch
-                    bstore(r_out, vo, (unsigned)((bd0 + (pl & 1)) * T::C + co_base + 2 * wave + (pl >> 1)) * plane_b, pv);
+                    bstore(r_out, vo, (unsigned)((bd0 + (pl & 1)) * T::C + row_chan(s, 2 * wave + (pl >> 1))) * plane_b, pv);
                 }
                 APZH_STAMP(3)
             };
