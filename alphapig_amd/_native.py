@@ -122,7 +122,7 @@ HIP_SYMBOLS = ["apz_last_error", "apz_version", "apz_device_count", "apz_create"
                "apz_layout_convert", "apz_bias_grad", "apz_add", "apz_load_weights_dev",
                "apz_sync", "apz_stream", "apz_set_forward_graphs",
                "apz_device_alloc", "apz_device_free", "apz_memcpy_h2d", "apz_memcpy_d2h",
-               "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms", "apz_prewarm", "apz_test_select_trunk", "apz_set_trunk_arith"]
+               "apz_conv3x3_bench", "apz_layer_io", "apz_set_profiling", "apz_kernel_time_ms", "apz_prewarm", "apz_test_select_trunk", "apz_set_trunk_arith", "apz_trunk_overflows"]
 
 
 def _one_hip_runtime():
@@ -276,6 +276,7 @@ def hip():
         "apz_prewarm": (C.c_int, [vp, C.c_int, C.c_int]),
         "apz_test_select_trunk": (C.c_int, [vp, C.c_int]),
         "apz_set_trunk_arith": (C.c_int, [vp, C.c_int]),
+        "apz_trunk_overflows": (C.c_long, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -20,6 +20,7 @@
 #include "trunk15_wino3.h"
 #include "trunk15_wino3s.h"
 #include "trunk15_wino3b.h"
+#include "trunk15_wino3h.h"
 #include "conv8_small.h"
 #include "wgrad_wino3.h"
 #include "sampler.h"
@@ -64,6 +65,8 @@ struct ConvLayer {
     float* upk2 = nullptr;  // trunk15_wino3_kernel: transformed weights G g G^T, [cot][row half][c4][lane][20] (wino_common.h)
     float* upk3s = nullptr; // trunk15_wino3s_kernel: the same values, [cot][wave][c4][piece][lane][4] (WinoPackSmall)
     void* upk3b = nullptr;  // trunk15_wino3b_kernel (apz_set_trunk_arith(APZ_ARITH_BF16X3) only): U as three bf16 terms (Wino3B)
+    void* upk3h = nullptr;  // trunk15_wino3h_kernel (APZ_ARITH_F16X2 only): U S[co] as two fp16 terms (Wino3H)
+    float* bias3h = nullptr;   // ... and its [128 biases][128 x 1 / S[co]]
     float* bias = nullptr;
 };
 
@@ -149,7 +152,15 @@ struct apz_engine {
     unsigned w3s_epoch = 0;                  // last epoch handed out; never 0, never repeated between two memsets of the words
     bool no_small_trunk = false;             // apz_test_select_trunk(APZ_TRUNK_WINOGRAD_BATCHED): tests compare the two forms
     bool no_quarter_trunk = false;           // apz_test_select_trunk(APZ_TRUNK_WINOGRAD_NO_QUARTER): 64-channel items for every batch
-    int trunk_arith = APZ_ARITH_F32;         // apz_set_trunk_arith: APZ_ARITH_BF16X3 = trunk15_wino3b_kernel for batches > 32
+    int trunk_arith = APZ_ARITH_F32;         // apz_set_trunk_arith: APZ_ARITH_BF16X3 / _F16X2 = the split kernels for batches > 32
+    // APZ_ARITH_F16X2: trunk15_wino3h_kernel raises a word when an activation left the fp16 range (a non-finite output);
+    // the words live in pinned host memory, one per submission slot + one for the synchronous entry points; the entry
+    // point that collects a forward's results looks at its word and repeats the forward on the exact-fp32 kernel.
+    unsigned* ovf_host = nullptr;            // [APZ_MAX_SLOTS + 1]
+    unsigned* ovf_dev = nullptr;             // the same words as the device sees them
+    unsigned* ovf_cur = nullptr;             // (device pointer) the word of the forward being queued
+    bool force_f32 = false;                  // the repeat of an overflowed forward
+    long ovf_repeats = 0;                    // forwards repeated so far (apz_trunk_overflows)
     int trunk_kernel = APZ_TRUNK_WINOGRAD;   // or APZ_TRUNK_DIRECT (trunk15_ring_kernel): apz_test_select_trunk, tests only
     // profiling
     bool profiling = false;
@@ -445,7 +456,33 @@ int launch_wino3b_t(apz_engine* e, int attr_slot, const ConvLayer& L, const floa
     return APZ_OK;
 }
 
+// The 2 x fp16 split kernel: same layouts, same grids, 512 threads
+template <bool RESID>
+int launch_wino3h_t(apz_engine* e, int attr_slot, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Wino3H;
+    bool& configured = e->lds_attr_set[attr_slot];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::trunk15_wino3h_kernel<RESID, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T::LDS_BYTES));
+        configured = true;
+    }
+    for (int b0 = 0; b0 < n; b0 += WINO3_MAX_BOARDS) {
+        const int nb = std::min(n - b0, WINO3_MAX_BOARDS);
+        const size_t off = (size_t)b0 * T::C * T::GPLANE;
+        const int grid = apz::wino3_grid(nb, e->num_cu);
+        hipLaunchKernelGGL((apz::trunk15_wino3h_kernel<RESID, true>), dim3(grid), dim3(512), T::LDS_BYTES, e->stream, in + off,
+                           (const void*)L.upk3h, L.bias3h, RESID ? resid + off : nullptr, out + off, nb, e->ovf_cur);
+    }
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    if (e->trunk_arith == APZ_ARITH_F16X2 && !e->force_f32 && L.upk3h && e->ovf_cur &&
+        (n > apz::Wino3S::MAX_BOARDS || e->no_small_trunk)) {
+        if (resid) return launch_wino3h_t<true>(e, 28, L, in, resid, out, n);
+        return launch_wino3h_t<false>(e, 29, L, in, resid, out, n);
+    }
     if (e->trunk_arith == APZ_ARITH_BF16X3 && L.upk3b && (n > apz::Wino3S::MAX_BOARDS || e->no_small_trunk)) {
         if (resid) return launch_wino3b_t<true>(e, 26, L, in, resid, out, n);
         return launch_wino3b_t<false>(e, 27, L, in, resid, out, n);
@@ -644,6 +681,40 @@ int forward_dev(apz_engine* e, const float* planes, int n, float* probs, float* 
     return APZ_OK;
 }
 
+// APZ_ARITH_F16X2: arms the synchronous overflow word for the scope (entry points that run trunk layers without collecting a
+// forward's results -- prewarm, the layer bench, apz_layer_io: the word is raised and nobody reads it)
+struct ArmOverflowWord {
+    apz_engine* e;
+    explicit ArmOverflowWord(apz_engine* e_) : e(e_) {
+        if (e->trunk_arith == APZ_ARITH_F16X2 && e->ovf_dev) e->ovf_cur = e->ovf_dev + APZ_MAX_SLOTS;
+    }
+    ~ArmOverflowWord() { e->ovf_cur = nullptr; }
+};
+
+// APZ_ARITH_F16X2: forward_dev with the overflow word `idx` armed.  `again` != nullptr: the forward is collected here --
+// wait for the stream, look at the word and, if an activation left the fp16 range, run `again` (the same forward, which
+// then takes the exact-fp32 trunk kernel).  Other arithmetics: plain forward_dev.
+template <class F>
+int forward_guarded(apz_engine* e, int idx, F run, bool collect) {
+    if (e->trunk_arith != APZ_ARITH_F16X2 || !e->ovf_host) return run();
+    e->ovf_host[idx] = 0;
+    e->ovf_cur = e->ovf_dev + idx;
+    int rc = run();
+    e->ovf_cur = nullptr;
+    if (rc || !collect) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->ovf_host[idx]) {
+        e->ovf_host[idx] = 0;
+        e->force_f32 = true;
+        rc = run();
+        e->force_f32 = false;
+        e->ovf_repeats++;
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return APZ_OK;
+}
+
 // dihedral index tables (train_mxnet.py:115-135) on square boards
 void build_perms(int N, std::vector<int>& ps, std::vector<int>& pp) {
     typedef std::vector<int> Grid;
@@ -692,6 +763,8 @@ void apz_destroy(apz_engine* e) {
         if (l.upk2) hipFree(l.upk2);
         if (l.upk3s) hipFree(l.upk3s);
         if (l.upk3b) hipFree(l.upk3b);
+        if (l.upk3h) hipFree(l.upk3h);
+        if (l.bias3h) hipFree(l.bias3h);
         if (l.wpk12) hipFree(l.wpk12);
         if (l.bias) hipFree(l.bias);
     }
@@ -701,6 +774,7 @@ void apz_destroy(apz_engine* e) {
                    e->wfc_raw, e->w3s_slabs, e->w3s_tickets};
     for (void* p : dev)
         if (p) hipFree(p);
+    if (e->ovf_host) hipHostFree(e->ovf_host);
     for (auto& sl : e->slots) {
         if (sl.h_codes) hipHostFree(sl.h_codes);
         if (sl.h_probs) hipHostFree(sl.h_probs);
@@ -907,6 +981,26 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
                 if (!L.upk3b) HIP_TRY(hipMalloc(&L.upk3b, apz::Wino3B::UPK_BYTES));
                 HIP_TRY(hipMemcpy(L.upk3b, ub.data(), apz::Wino3B::UPK_BYTES, hipMemcpyHostToDevice));
             }
+            if (e->trunk_arith == APZ_ARITH_F16X2) {
+                // the same U, per output channel times a power of two, as two fp16 terms: trunk15_wino3h.h
+                std::vector<uint16_t> uh;
+                std::vector<float> b3(apz::Wino3H::BIAS_FLOATS);
+                for (int o = 0; o < 128; o++) b3[o] = (float)shift[o];
+                apz::wino3h_pack_host(
+                    [&](int co, int ci, int pos) {
+                        double g[3][3], t[3];
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) g[a][b] = (double)w[((size_t)co * 128 + ci) * 9 + a * 3 + b] * scale[co];
+                        const int i = pos / 6, k = pos % 6;
+                        for (int b = 0; b < 3; b++) t[b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+                        return t[0] * G[k][0] + t[1] * G[k][1] + t[2] * G[k][2];
+                    },
+                    uh, b3.data() + 128);
+                if (!L.upk3h) HIP_TRY(hipMalloc(&L.upk3h, apz::Wino3H::UPK_BYTES));
+                HIP_TRY(hipMemcpy(L.upk3h, uh.data(), apz::Wino3H::UPK_BYTES, hipMemcpyHostToDevice));
+                rc = upload(&L.bias3h, b3);
+                if (rc) return rc;
+            }
         }
     }
     // heads: two 1x1 conv_act (fix_gamma default) folded into one [6][C] matrix
@@ -957,8 +1051,11 @@ int apz_forward(apz_engine* e, const void* planes_dev, int n, void* probs_dev, v
     if (!e || !planes_dev || !probs_dev || !values_dev) return fail(APZ_E_ARG, "null argument");
     EngineLock guard(e->submit_lock);
     HIP_TRY(hipSetDevice(e->cfg.device));
-    return forward_dev(e, (const float*)planes_dev, n, (float*)probs_dev, (float*)values_dev, (float*)logits_dev,
-                       (float*)vlogits_dev);
+    // (APZ_ARITH_F16X2: returns with the stream drained -- the overflow word has to be read before the results are used)
+    return forward_guarded(e, APZ_MAX_SLOTS, [&]() {
+        return forward_dev(e, (const float*)planes_dev, n, (float*)probs_dev, (float*)values_dev, (float*)logits_dev,
+                           (float*)vlogits_dev);
+    }, true);
 }
 
 int apz_forward_host(apz_engine* e, const float* planes_host, int n, float* probs_host, float* values_host) {
@@ -970,7 +1067,7 @@ int apz_forward_host(apz_engine* e, const float* planes_host, int n, float* prob
     const size_t hw = e->hw, pin = (size_t)n * e->cfg.c_in * hw * sizeof(float);
     std::memcpy(e->h_planes, planes_host, pin);
     HIP_TRY(hipMemcpyAsync(e->planes, e->h_planes, pin, hipMemcpyHostToDevice, e->stream));
-    int rc = forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
+    int rc = forward_guarded(e, APZ_MAX_SLOTS, [&]() { return forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr); }, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_probs, e->probs, n * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_values, e->values, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -991,14 +1088,12 @@ int apz_forward_codes_async(apz_engine* e, const uint8_t* codes_pinned, int n, f
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t hw = e->hw;
     HIP_TRY(hipMemcpyAsync(e->codes, codes_pinned, (size_t)n * e->code_stride, hipMemcpyHostToDevice, e->stream));
-    int rc;
-    if (stem_takes_codes(e)) {
-        rc = forward_dev(e, nullptr, n, e->probs, e->values, nullptr, nullptr, e->codes);
-    } else {
-        rc = apz_encode_planes(e, e->codes, n, e->cfg.c_in, e->planes);
-        if (rc) return rc;
-        rc = forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
-    }
+    // (APZ_ARITH_F16X2: the forward is collected here, see forward_guarded -- the copies below are queued behind it)
+    int rc = forward_guarded(e, APZ_MAX_SLOTS, [&]() -> int {
+        if (stem_takes_codes(e)) return forward_dev(e, nullptr, n, e->probs, e->values, nullptr, nullptr, e->codes);
+        if (int r = apz_encode_planes(e, e->codes, n, e->cfg.c_in, e->planes)) return r;
+        return forward_dev(e, e->planes, n, e->probs, e->values, nullptr, nullptr);
+    }, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(probs_pinned, e->probs, n * hw * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(values_pinned, e->values, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -1053,6 +1148,14 @@ int apz_submit_codes(apz_engine* e, int slot, const uint8_t* codes_host, int n) 
         return forward_dev(e, e->planes, n, sl.d_probs, sl.d_values, nullptr, nullptr);
     };
     int rc = APZ_OK;
+    if (e->trunk_arith == APZ_ARITH_F16X2 && e->ovf_host) {   // the slot's overflow word: read by apz_wait
+        e->ovf_host[slot] = 0;
+        e->ovf_cur = e->ovf_dev + slot;
+    }
+    struct Disarm {
+        apz_engine* e;
+        ~Disarm() { e->ovf_cur = nullptr; }
+    } disarm{e};
     const long key = ((long)slot << 32) | (long)n;
     const bool graphable = e->use_graphs && !e->profiling && n <= FWD_GRAPH_MAX_BOARDS && e->loaded;
     auto it = graphable ? e->fwd_graphs.find(key) : e->fwd_graphs.end();
@@ -1100,6 +1203,23 @@ int apz_wait(apz_engine* e, int slot, float* probs_host, float* values_host) {
     if (!sl.busy) return fail(APZ_E_STATE, "nothing submitted in this slot");
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipEventSynchronize(sl.done));
+    if (e->ovf_host && e->ovf_host[slot]) {
+        // an activation of this batch left the fp16 range (trunk15_wino3h.h): the same batch again on the exact-fp32 kernel
+        EngineLock guard(e->submit_lock);
+        e->ovf_host[slot] = 0;
+        e->force_f32 = true;
+        int rc;
+        if (stem_takes_codes(e)) {
+            rc = forward_dev(e, nullptr, sl.n, sl.d_probs, sl.d_values, nullptr, nullptr, sl.d_codes);
+        } else {
+            rc = apz_encode_planes(e, sl.d_codes, sl.n, e->cfg.c_in, e->planes);
+            if (!rc) rc = forward_dev(e, e->planes, sl.n, sl.d_probs, sl.d_values, nullptr, nullptr);
+        }
+        e->force_f32 = false;
+        e->ovf_repeats++;
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     std::memcpy(probs_host, sl.h_probs, (size_t)sl.n * e->hw * sizeof(float));
     std::memcpy(values_host, sl.h_values, (size_t)sl.n * sizeof(float));
     sl.busy = false;
@@ -1284,6 +1404,12 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
                 if (!L.upk3b) HIP_TRY(hipMalloc(&L.upk3b, apz::Wino3B::UPK_BYTES));
                 hipLaunchKernelGGL(apz::pack_wino3b_folded_kernel, dim3(128 * 128 / 256), dim3(256), 0, st, w, scale,
                                    (unsigned short*)L.upk3b);
+            }
+            if (x4 && e->trunk_arith == APZ_ARITH_F16X2) {
+                if (!L.upk3h) HIP_TRY(hipMalloc(&L.upk3h, apz::Wino3H::UPK_BYTES));
+                if (!L.bias3h) HIP_TRY(hipMalloc(&L.bias3h, apz::Wino3H::BIAS_FLOATS * sizeof(float)));
+                hipLaunchKernelGGL(apz::pack_wino3h_folded_kernel, dim3(128), dim3(128), 0, st, w, scale, shift,
+                                   (unsigned short*)L.upk3h, L.bias3h);
             }
             if (e->small8 && L.wpk12)
                 hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale,
@@ -1907,6 +2033,7 @@ int apz_prewarm(apz_engine* e, int n, int iters) {
     if (!e->loaded) return fail(APZ_E_STATE, "weights not loaded");
     HIP_TRY(hipSetDevice(e->cfg.device));
     // e->codes is zero-filled at creation and only ever overwritten with valid codes: any content is a legal input
+    ArmOverflowWord arm(e);
     for (int i = 0; i < iters; i++) {
         int rc;
         if (stem_takes_codes(e)) {
@@ -1972,6 +2099,7 @@ int apz_conv3x3_bench(apz_engine* e, int layer, int n, int iters, int warmup, fl
     HIP_TRY(hipSetDevice(e->cfg.device));
     const bool was = e->profiling;
     e->profiling = false;
+    ArmOverflowWord arm(e);
     // produce this layer's real input from the planes resident in e->planes
     const float* in = e->planes;
     if (layer > 0) {
@@ -2017,6 +2145,7 @@ int apz_layer_io(apz_engine* e, int layer, float* host_out, int64_t count) {
     float* buf = nullptr;
     const bool was = e->profiling;
     e->profiling = false;
+    ArmOverflowWord arm(e);
     int rc = run_trunk(e, e->planes, e->last_n, layer, &buf);
     e->profiling = was;
     if (rc) return rc;
@@ -2040,15 +2169,24 @@ int apz_set_trunk_arith(apz_engine* e, int arith) {
         EngineLock guard_(e->submit_lock);
         drop_forward_graphs(e);
     }
-    if (!e || (arith != APZ_ARITH_F32 && arith != APZ_ARITH_BF16X3)) return fail(APZ_E_ARG, "bad trunk arithmetic");
+    if (!e || (arith != APZ_ARITH_F32 && arith != APZ_ARITH_BF16X3 && arith != APZ_ARITH_F16X2))
+        return fail(APZ_E_ARG, "bad trunk arithmetic");
     EngineLock guard(e->submit_lock);
-    if (arith == APZ_ARITH_BF16X3 && !e->ring)
-        return fail(APZ_E_UNSUPPORTED, "the bf16 x 3 trunk kernel exists for the 15x15 / 128-filter residual net only");
+    if (arith != APZ_ARITH_F32 && !e->ring)
+        return fail(APZ_E_UNSUPPORTED, "the split trunk kernels exist for the 15x15 / 128-filter residual net only");
+    if (arith == APZ_ARITH_F16X2 && !e->ovf_host) {
+        HIP_TRY(hipSetDevice(e->cfg.device));
+        HIP_TRY(hipHostMalloc((void**)&e->ovf_host, (APZ_MAX_SLOTS + 1) * sizeof(unsigned), hipHostMallocMapped));
+        std::memset(e->ovf_host, 0, (APZ_MAX_SLOTS + 1) * sizeof(unsigned));
+        HIP_TRY(hipHostGetDevicePointer((void**)&e->ovf_dev, e->ovf_host, 0));
+    }
     if (e->loaded && arith != e->trunk_arith)
         return fail(APZ_E_STATE, "apz_set_trunk_arith must be called before the weights are loaded");
     e->trunk_arith = arith;
     return APZ_OK;
 }
+
+long apz_trunk_overflows(apz_engine* e) { return e ? e->ovf_repeats : -1; }
 
 int apz_test_select_trunk(apz_engine* e, int kind) {
     if (e) {

@@ -586,7 +586,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
         run(std::integral_constant<int, 0>{});
     else
         run(std::integral_constant<int, 1>{});
-    if (nonfinite && flag) atomicOr(flag, 1u);
+    // (a plain store: every writer writes the same 1, and the word may live in pinned host memory)
+    if (nonfinite && flag) *reinterpret_cast<volatile unsigned*>(flag) = 1u;
 #ifdef APZ_WINO3H_STAMPS
     st_acc[7] = __builtin_readcyclecounter() - st_t0;
     st_acc[6] = __builtin_amdgcn_s_memrealtime() - st_r0;

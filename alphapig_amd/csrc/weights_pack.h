@@ -5,6 +5,7 @@
 // Winograd packing on one core and the upload; these kernels take a few tens of microseconds.  gfx950.
 #pragma once
 #include "trunk15_wino3b.h"
+#include "trunk15_wino3h.h"
 #include "wino_common.h"
 #include <hip/hip_runtime.h>
 
@@ -102,6 +103,53 @@ __global__ void pack_wino3b_folded_kernel(const float* __restrict__ w, const dou
                 rem -= (double)__builtin_bit_cast(float, u);
             }
         }
+}
+
+// The same U for trunk15_wino3h.h: one workgroup per output channel (thread = input channel) finds max |U| of the channel,
+// S = Wino3H::scale_for(max), and writes U S as two fp16 terms (both round to nearest even, the remainder in double) at
+// Wino3H::upk_offset; bias3h = [128 folded biases][128 x 1 / S].  Launch: grid 128, block 128.
+__global__ void pack_wino3h_folded_kernel(const float* __restrict__ w, const double* __restrict__ scale, const double* __restrict__ shift,
+                                          unsigned short* __restrict__ up, float* __restrict__ bias3h) {
+    const int co = blockIdx.x, ci = threadIdx.x;
+    const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double g[3][3], t[6][3], u[36];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) g[a][b] = (double)w[((size_t)co * 128 + ci) * 9 + a * 3 + b] * scale[co];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            u[6 * i + k] = t[i][0] * G[k][0] + t[i][1] * G[k][1] + t[i][2] * G[k][2];
+            m = fmax(m, fabs(u[6 * i + k]));
+        }
+    __shared__ double red[128];
+    red[ci] = m;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+        if (ci < s) red[ci] = fmax(red[ci], red[ci + s]);
+        __syncthreads();
+    }
+    const float S = Wino3H::scale_for(red[0]);
+    if (ci == 0) {
+        bias3h[co] = (float)shift[co];
+        bias3h[128 + co] = 1.f / S;
+    }
+#pragma unroll
+    for (int pos = 0; pos < 36; pos++) {
+        const double x = u[pos] * (double)S;
+        const _Float16 hi = (_Float16)(float)x;
+        const _Float16 lo = (_Float16)(float)(x - (double)(float)hi);
+        up[Wino3H::upk_offset(co, ci, pos, 0) / 2] = __builtin_bit_cast(unsigned short, hi);
+        up[Wino3H::upk_offset(co, ci, pos, 1) / 2] = __builtin_bit_cast(unsigned short, lo);
+    }
 }
 
 // heads: rows [row0, row0 + rows) of the [6][C] matrix of both 1x1 convolutions, and their folded biases

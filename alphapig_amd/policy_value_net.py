@@ -27,10 +27,16 @@ class EvaluatorError(RuntimeError):
 
 class PolicyValueNet(object):
     def __init__(self, board_width, board_height, batch_size=512, n_blocks=8, n_filter=128,
-                 model_params=None, net_kind="resnet", c_in=9, device=0, seed=0, init_style="reference", trunk_arith="f32"):
-        """trunk_arith: "f32" (default: exact fp32 products, the bits the parity tests rest on) or "bf16x3" -- batches of
-        more than 32 boards of the 15x15 / 128-filter residual net then run csrc/trunk15_wino3b.h: every fp32 operand as
-        three bf16 terms on the bf16 matrix pipe, fp32 accumulation; fp32-accurate, different low-order bits."""
+                 model_params=None, net_kind="resnet", c_in=9, device=0, seed=0, init_style="reference", trunk_arith="auto"):
+        """trunk_arith: the arithmetic of the 128 -> 128 trunk convolutions of the 15x15 / 128-filter residual net on
+        batches of more than 32 boards (smaller batches and every other net always compute exact fp32 products):
+          "f32"    exact fp32 products on the fp32 matrix pipe (csrc/trunk15_wino3.h): the bits the parity tests rest on;
+          "f16x2"  every fp32 operand as two fp16 terms on the fp16 matrix pipe, fp32 accumulation (csrc/trunk15_wino3h.h):
+                   the same accuracy class (<= 1e-4 on the logits against the float64 oracle, tests/test_gpu_winograd_
+                   numerics.py), different low-order bits, 1.5x faster; an activation beyond the fp16 range makes the
+                   engine repeat that forward on the exact kernel (never a silently wrong result);
+          "bf16x3" three bf16 terms, six products (csrc/trunk15_wino3b.h): round 4's form, kept for comparison;
+          "auto"   (default) "f16x2" where that kernel exists (15x15, 128 filters, residual net), else "f32"."""
         self.L = _native.hip()
         self.board_width, self.board_height = int(board_width), int(board_height)
         self.batchsize = int(batch_size)
@@ -47,11 +53,14 @@ class PolicyValueNet(object):
         self._h = self.L.apz_create(C.byref(cfg))
         if not self._h:
             raise EvaluatorError("apz_create failed: %s" % self.L.apz_last_error().decode())
-        if trunk_arith not in ("f32", "bf16x3"):
-            raise ValueError("trunk_arith must be 'f32' or 'bf16x3'")
+        if trunk_arith not in ("auto", "f32", "bf16x3", "f16x2"):
+            raise ValueError("trunk_arith must be 'auto', 'f32', 'f16x2' or 'bf16x3'")
+        if trunk_arith == "auto":
+            split_ok = (net_kind == "resnet" and self.board_width == 15 and self.board_height == 15 and self._n_filter == 128)
+            trunk_arith = "f16x2" if split_ok else "f32"
         self.trunk_arith = trunk_arith
-        if trunk_arith == "bf16x3":
-            self._ck(self.L.apz_set_trunk_arith(self._h, 1))         # before the weights are loaded: they are packed for it
+        if trunk_arith != "f32":                                     # before the weights are loaded: they are packed for it
+            self._ck(self.L.apz_set_trunk_arith(self._h, {"bf16x3": 1, "f16x2": 2}[trunk_arith]))
         if model_params is None:
             model_params = weights.init_params(net_kind, self.board_height, self.board_width, self.channelnum,
                                                self._n_blocks, self._n_filter, seed=seed, style=init_style)
@@ -329,6 +338,11 @@ class PolicyValueNet(object):
         out = np.zeros(2, dtype=np.float32)
         self._ck(self.L.apz_kernel_time_ms(self._h, KERNEL_CLASSES[kernel_class], as_ptr(out, C.c_float)))
         return float(out[0]), int(out[1])
+
+    def trunk_overflows(self):
+        """Forwards the engine repeated on the exact-fp32 trunk kernel because an activation left the fp16 range
+        (trunk_arith "f16x2"; always 0 for the other arithmetics)."""
+        return int(self.L.apz_trunk_overflows(self._h))
 
     def prewarm(self, n, iters):
         """Enqueue `iters` forwards of n empty boards on the engine stream, without waiting (GPU-only warm-up of a

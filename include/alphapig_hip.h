@@ -293,10 +293,18 @@ int apz_set_profiling(apz_engine *e, int on);
  * chosen BEFORE apz_load_weights.  APZ_ARITH_F32 (default): exact fp32 products on the fp32 matrix pipe -- the bits the
  * parity tests rest on.  APZ_ARITH_BF16X3: batches of more than 32 boards run csrc/trunk15_wino3b.h -- every fp32 operand
  * as three bf16 terms, six bf16 products per fp32 product, fp32 accumulation: fp32-accurate (tests/
- * test_gpu_winograd_numerics.py), different low-order bits. */
+ * test_gpu_winograd_numerics.py), different low-order bits.  APZ_ARITH_F16X2 (round 6): batches of more than 32 boards run
+ * csrc/trunk15_wino3h.h -- every fp32 operand as two fp16 terms (weights times a per-channel power of two), three products
+ * per fp32 product on the fp16 matrix pipe, fp32 accumulation: the same accuracy class, 1.5x the exact kernel's speed.
+ * An activation beyond the fp16 range (|x| > ~655) shows as a non-finite output; the kernel raises a word and the entry
+ * point that collects the forward (apz_wait, apz_forward_host, apz_forward_codes_host, apz_forward, apz_forward_codes_async
+ * -- the last two then return with the stream drained) repeats it on the exact-fp32 kernel: results are always finite-
+ * checked, never silently wrong.  apz_trunk_overflows: how many forwards were repeated. */
 #define APZ_ARITH_F32 0
 #define APZ_ARITH_BF16X3 1
+#define APZ_ARITH_F16X2 2
 int apz_set_trunk_arith(apz_engine *e, int arith);
+long apz_trunk_overflows(apz_engine *e);
 #define APZ_TRUNK_DIRECT 0
 #define APZ_TRUNK_WINOGRAD 3            /* default: batches of <= 32 boards take the small-batch form (csrc/trunk15_wino3s.h) */
 #define APZ_TRUNK_WINOGRAD_BATCHED 4    /* ... the batched form for every batch size (the tests hold the two forms to bit equality) */

@@ -37,7 +37,9 @@ def random_positions(n, w, c=9, seed=1234):
 def resnet3():
     from alphapig_amd.policy_value_net import PolicyValueNet
     prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=5, style="bench")
-    net = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm)
+    # trunk_arith "f32": these tests compare bits across batch sizes (the default, "auto" = "f16x2", computes batches of more
+    # than 32 boards on the fp16 x 2 split kernel and smaller ones on the exact kernel: same accuracy class, different low bits)
+    net = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm, trunk_arith="f32")
     yield net, prm
     net.close()
 
@@ -81,12 +83,12 @@ def test_resnet_layers_and_heads(resnet3, n):
     np.testing.assert_allclose(net.layer_output(6, n), o_trunk, rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("kind", ["wino3", "wino3-batched", "wino3b"])
+@pytest.mark.parametrize("kind", ["wino3", "wino3-batched", "wino3b", "wino3h"])
 def test_resnet_full_depth_10_blocks(kind):
     """The 10-block net (train_mxnet.py:79-91) against the float64 oracle on every Winograd trunk kernel: 24 boards
     take trunk15_wino3s_kernel by default ("wino3"); "wino3-batched" forces trunk15_wino3_kernel, the kernel the
     self-play bench spends 97 % of its GPU time in, onto the same batch; "wino3b" = trunk_arith "bf16x3", the 3 x bf16
-    split kernel forced onto it."""
+    split kernel forced onto it; "wino3h" = trunk_arith "f16x2", the 2 x fp16 split kernel (the default for batches > 32)."""
     prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
     net = _net_with_trunk_kernel(kind, prm, 10, 32)
     _, planes = random_positions(24, 15, seed=7)
@@ -110,7 +112,7 @@ def test_bench_launch_shape_10_blocks_512_boards_against_oracle():
     the same boards evaluated alone in a small launch (which the tests above hold to the oracle as well)."""
     prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
     from alphapig_amd.policy_value_net import PolicyValueNet
-    net = PolicyValueNet(15, 15, batch_size=512, n_blocks=10, n_filter=128, model_params=prm)
+    net = PolicyValueNet(15, 15, batch_size=512, n_blocks=10, n_filter=128, model_params=prm, trunk_arith="f32")
     _, planes = random_positions(512, 15, seed=4242)
     logits, probs, vlog, vals = net.forward_with_logits(planes)
     rows = sorted(set([0, 1, 255, 256, 510, 511]) | set(np.random.RandomState(9).permutation(512)[:26].tolist()))
@@ -223,6 +225,15 @@ def test_batch_larger_than_max_and_errors(resnet3):
     p, v = net.forward_planes(planes)
     p1, v1 = net.forward_planes(planes[100:101])
     np.testing.assert_array_equal(p[100], p1[0])
+    from alphapig_amd.policy_value_net import PolicyValueNet as _PVN
+    auto = _PVN(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm)       # the default arithmetic
+    assert auto.trunk_arith == "f16x2"
+    pa, va = auto.forward_planes(planes)
+    np.testing.assert_allclose(pa, p, rtol=0, atol=2e-6)            # 64-board chunks on the split kernel: the same values
+    np.testing.assert_allclose(va, v, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(auto.forward_planes(planes[100:101])[0], p1)   # one board: the exact kernel, the same bits
+    assert auto.trunk_overflows() == 0
+    auto.close()
     with pytest.raises(ValueError):
         net.forward_planes(np.zeros((2, 9, 8, 8), np.float32))
     from alphapig_amd.policy_value_net import EvaluatorError, PolicyValueNet
@@ -331,11 +342,12 @@ def _net_with_trunk_kernel(kind, prm, n_blocks, batch):
     """kind "ring" = the direct convolution (trunk15_ring_kernel: exact fp32 FMA chains, the in-tree cross-check), "wino3" = the
     fused F(4x4,3x3) Winograd kernel (default); selected through the C ABI's test hook apz_test_select_trunk."""
     from alphapig_amd.policy_value_net import PolicyValueNet
-    if kind == "wino3b":      # the 3 x bf16 split kernel (constructor flag), forced onto batches of every size
-        net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm, trunk_arith="bf16x3")
+    if kind in ("wino3b", "wino3h"):   # the split kernels (constructor flag), forced onto batches of every size
+        net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm,
+                             trunk_arith={"wino3b": "bf16x3", "wino3h": "f16x2"}[kind])
         net._ck(net.L.apz_test_select_trunk(net._h, 4))
         return net
-    net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm)
+    net = PolicyValueNet(15, 15, batch_size=batch, n_blocks=n_blocks, n_filter=128, model_params=prm, trunk_arith="f32")
     net._ck(net.L.apz_test_select_trunk(net._h, {"ring": 0, "wino3": 3, "wino3-batched": 4}[kind]))
     return net
 
@@ -398,8 +410,8 @@ def test_small_batch_trunk_kernel_gives_the_batched_kernels_bits(n):
     from alphapig_amd.policy_value_net import PolicyValueNet
     prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=15, style="bench")
     _, planes = random_positions(n, 15, seed=500 + n)
-    small = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm)
-    batched = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm)
+    small = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm, trunk_arith="f32")
+    batched = PolicyValueNet(15, 15, batch_size=64, n_blocks=3, n_filter=128, model_params=prm, trunk_arith="f32")
     batched._ck(batched.L.apz_test_select_trunk(batched._h, 4))
     a = small.forward_with_logits(planes)
     b = batched.forward_with_logits(planes)
@@ -423,11 +435,11 @@ def test_small_batch_kernel_in_launch_reduction_over_thousands_of_mixed_launches
     from alphapig_amd.policy_value_net import PolicyValueNet
     prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=16, style="bench")
     _, planes = random_positions(32, 15, seed=901)
-    batched = PolicyValueNet(15, 15, batch_size=32, n_blocks=3, n_filter=128, model_params=prm)
+    batched = PolicyValueNet(15, 15, batch_size=32, n_blocks=3, n_filter=128, model_params=prm, trunk_arith="f32")
     batched._ck(batched.L.apz_test_select_trunk(batched._h, 4))
     ref_p, ref_v = batched.forward_planes(planes)
     batched.close()
-    small = PolicyValueNet(15, 15, batch_size=32, n_blocks=3, n_filter=128, model_params=prm)
+    small = PolicyValueNet(15, 15, batch_size=32, n_blocks=3, n_filter=128, model_params=prm, trunk_arith="f32")
     sizes = [1, 32, 2, 7, 31, 3, 16, 1, 24, 5]
     rs = np.random.RandomState(4)
     for it in range(500):                                   # 500 forwards x 6 trunk launches
@@ -490,7 +502,7 @@ def test_wino3_launch_shapes_do_not_change_a_boards_bits():
     (policy_value_net_mxnet.py:77-83 through policy_value, :232-242)."""
     from alphapig_amd.policy_value_net import PolicyValueNet
     prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=14, style="bench")
-    net = PolicyValueNet(15, 15, batch_size=600, n_blocks=2, n_filter=128, model_params=prm)
+    net = PolicyValueNet(15, 15, batch_size=600, n_blocks=2, n_filter=128, model_params=prm, trunk_arith="f32")
     _, planes = random_positions(600, 15, seed=88)
     big = net.forward_with_logits(planes)                        # 300 pairs: one workgroup per CU
     # 33 ... 128 boards: QUARTER items (four workgroups per pair, 32 output channels each: csrc/trunk15_wino3.h)
@@ -510,13 +522,15 @@ def test_wino3_launch_shapes_do_not_change_a_boards_bits():
     net.close()
 
 
-def test_bf16x3_trunk_10_blocks_512_boards_and_launch_shapes():
-    """The opt-in 3 x bf16 split trunk (csrc/trunk15_wino3b.h, PolicyValueNet(trunk_arith="bf16x3")) at the bench's launch
-    shape: 10 blocks, 512 boards in one forward, rows at both ends / around the middle / 26 random ones against the float64
-    oracle at north_star's 1e-4 (policy_value_net_mxnet.py:70-102) -- and a board's bits do not depend on the launch shape
-    (1 ... 300 boards, odd batches, fewer pairs than CUs), nor on its place in the batch."""
+@pytest.mark.parametrize("kind,arith", [("wino3h", "f16x2"), ("wino3b", "bf16x3")])
+def test_split_trunk_10_blocks_512_boards_and_launch_shapes(kind, arith):
+    """The split trunk kernels -- 2 x fp16 (csrc/trunk15_wino3h.h, trunk_arith "f16x2": the default for batches > 32) and
+    3 x bf16 (csrc/trunk15_wino3b.h, "bf16x3") -- at the bench's launch shape: 10 blocks, 512 boards in one forward, rows at
+    both ends / around the middle / 26 random ones against the float64 oracle at north_star's 1e-4
+    (policy_value_net_mxnet.py:70-102) -- and a board's bits do not depend on the launch shape (1 ... 300 boards, odd
+    batches, fewer pairs than CUs), nor on its place in the batch."""
     prm = weights.init_params("resnet", 15, 15, 9, 10, 128, seed=0, style="bench")
-    net = _net_with_trunk_kernel("wino3b", prm, 10, 512)
+    net = _net_with_trunk_kernel(kind, prm, 10, 512)
     _, planes = random_positions(512, 15, seed=4242)
     logits, probs, vlog, vals = net.forward_with_logits(planes)
     rows = sorted(set([0, 1, 255, 256, 510, 511]) | set(np.random.RandomState(9).permutation(512)[:26].tolist()))
@@ -534,26 +548,29 @@ def test_bf16x3_trunk_10_blocks_512_boards_and_launch_shapes():
     np.testing.assert_array_equal(p2[0], logits[perm])
     # without the test hook the constructor flag leaves batches of <= 32 boards on the exact-fp32 small-batch kernel
     from alphapig_amd.policy_value_net import PolicyValueNet
-    plain = PolicyValueNet(15, 15, batch_size=64, n_blocks=10, n_filter=128, model_params=prm)
-    flagged = PolicyValueNet(15, 15, batch_size=64, n_blocks=10, n_filter=128, model_params=prm, trunk_arith="bf16x3")
+    plain = PolicyValueNet(15, 15, batch_size=64, n_blocks=10, n_filter=128, model_params=prm, trunk_arith="f32")
+    flagged = PolicyValueNet(15, 15, batch_size=64, n_blocks=10, n_filter=128, model_params=prm, trunk_arith=arith)
     np.testing.assert_array_equal(plain.forward_with_logits(planes[:8])[0], flagged.forward_with_logits(planes[:8])[0])
     big = flagged.forward_with_logits(planes[:64])[0]
     np.testing.assert_allclose(big, logits[:64], rtol=0, atol=0)            # 64 boards: the split kernel, the same bits as in the 512 batch
+    assert net.trunk_overflows() == 0 and flagged.trunk_overflows() == 0
     for x in (net, plain, flagged):
         x.close()
 
 
-def test_bf16x3_weights_packed_on_the_device_equal_the_host_pack():
-    """The trainer's refresh path (apz_load_weights_dev, policy_value_net_mxnet.py:295-297) packs the three bf16 terms of
-    U = G g G^T with a kernel; the constructor packs them on the host.  Same double arithmetic, same rounding: the two
-    evaluators give identical bits -- also after the weights change."""
+@pytest.mark.parametrize("arith", ["f16x2", "bf16x3"])
+def test_split_weights_packed_on_the_device_equal_the_host_pack(arith):
+    """The trainer's refresh path (apz_load_weights_dev, policy_value_net_mxnet.py:295-297) packs the split terms of
+    U = G g G^T (two fp16 terms of U S[co] and the per-channel scales / three bf16 terms) with a kernel; the constructor
+    packs them on the host.  Same double arithmetic, same rounding: the two evaluators give identical bits -- also after
+    the weights change."""
     torch = pytest.importorskip("torch")
     from alphapig_amd.policy_value_net import PolicyValueNet
     prm = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=31, style="bench")
     prm2 = weights.init_params("resnet", 15, 15, 9, 3, 128, seed=32, style="bench")
     _, planes = random_positions(70, 15, seed=77)
-    host = PolicyValueNet(15, 15, batch_size=128, n_blocks=3, n_filter=128, model_params=prm, trunk_arith="bf16x3")
-    dev = PolicyValueNet(15, 15, batch_size=128, n_blocks=3, n_filter=128, model_params=prm2, trunk_arith="bf16x3")
+    host = PolicyValueNet(15, 15, batch_size=128, n_blocks=3, n_filter=128, model_params=prm, trunk_arith=arith)
+    dev = PolicyValueNet(15, 15, batch_size=128, n_blocks=3, n_filter=128, model_params=prm2, trunk_arith=arith)
     tensors = {k: torch.tensor(np.ascontiguousarray(v, dtype=np.float32), device="cuda") for k, v in prm.items()}
     dev.load_device_params(tensors)
     a, b = host.forward_with_logits(planes), dev.forward_with_logits(planes)
@@ -570,6 +587,58 @@ def test_bf16x3_weights_packed_on_the_device_equal_the_host_pack():
         host._ck(host.L.apz_set_trunk_arith(host._h, 0))
     host.close()
     dev.close()
+
+
+@pytest.mark.gpu
+def test_f16x2_overflow_repeats_the_forward_on_the_exact_kernel():
+    """trunk_arith "f16x2": an activation beyond the fp16 range (|x| > ~655: |V| = |B^T d B| <= 100 |x| overflows the split)
+    gives a non-finite trunk output; the kernel raises the forward's word and the entry point that collects the results
+    repeats the forward on the exact-fp32 kernel (include/alphapig_hip.h, apz_set_trunk_arith) -- through every entry point
+    the Python mirror uses, with the bits of a trunk_arith="f32" evaluator, and never a silent clamp to 0
+    (policy_value_net_mxnet.py:77-83: the reference's fp32 convolution has no such range)."""
+    from alphapig_amd.policy_value_net import PolicyValueNet
+    from alphapig_amd.game import Board
+    prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=41, style="bench")
+    big = dict(prm)
+    big["res_conv1_weight"] = np.asarray(prm["res_conv1_weight"], np.float32) * 3.0e4   # stem outputs in the tens of thousands
+    _, planes = random_positions(40, 15, seed=8)
+    exact = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=big, trunk_arith="f32")
+    split = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=big, trunk_arith="f16x2")
+    assert split.trunk_overflows() == 0
+    a, b = exact.forward_with_logits(planes), split.forward_with_logits(planes)          # apz_forward
+    assert split.trunk_overflows() == 1
+    for x, y in zip(a, b):
+        assert np.isfinite(np.asarray(y)).all()
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    pa, pb = exact.forward_planes(planes), split.forward_planes(planes)                 # apz_forward_host
+    assert split.trunk_overflows() == 2
+    np.testing.assert_array_equal(pa[0], pb[0])
+    boards = []
+    rs = np.random.RandomState(3)
+    for g in range(40):
+        bd = Board(width=15, height=15, n_in_row=5)
+        bd.init_board(0)
+        for m in rs.permutation(225)[:6 + g % 5]:
+            bd.do_move(int(m))
+        boards.append(bd.position_codes())
+    codes = np.stack(boards)
+    ca, cb = exact.evaluate_codes(codes), split.evaluate_codes(codes)                   # apz_forward_codes_host
+    assert split.trunk_overflows() == 3
+    np.testing.assert_array_equal(ca[0], cb[0])
+    np.testing.assert_array_equal(ca[1], cb[1])
+    sa, sb = exact.evaluate_codes_slot(1, codes), split.evaluate_codes_slot(1, codes)   # apz_submit_codes / apz_wait
+    assert split.trunk_overflows() == 4
+    np.testing.assert_array_equal(sa[0], sb[0])
+    np.testing.assert_array_equal(sa[1], sb[1])
+    # ordinary weights afterwards: no repeat, the split kernel's own results
+    split.set_params(prm)
+    exact.set_params(prm)
+    q = split.forward_with_logits(planes)
+    assert split.trunk_overflows() == 4
+    o = net_ref.forward(prm, planes, "resnet", 2, np.float64)
+    np.testing.assert_allclose(q[0], o[0], rtol=0, atol=LOGIT_ATOL)
+    exact.close()
+    split.close()
 
 
 @pytest.mark.gpu

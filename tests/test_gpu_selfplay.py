@@ -58,7 +58,7 @@ class Never(object):
         return 1.0
 
 
-@pytest.mark.parametrize("cfg", ["simple8", "resnet15", "resnet15-bf16x3"])
+@pytest.mark.parametrize("cfg", ["simple8", "resnet15", "resnet15-bf16x3", "resnet15-f16x2"])
 def test_engine_on_gpu_equals_sequential_oracle_on_recorded_outputs(cfg):
     from alphapig_amd.policy_value_net import PolicyValueNet
     if cfg == "simple8":      # BASELINE config 2 shape: 8x8, 4-in-row, simple net
@@ -71,10 +71,10 @@ def test_engine_on_gpu_equals_sequential_oracle_on_recorded_outputs(cfg):
         prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=2, style="bench")
         net = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=prm)
         forced = True
-    else:                     # ... on the 3 x bf16 split trunk: 80 concurrent games = 40-board batches (the split kernel takes batches > 32)
+    else:                     # ... on the split trunk kernels: 80 concurrent games = 40-board batches (they take batches > 32)
         w, nrow, npl, G, total = 15, 5, 24, 80, 80
         prm = weights.init_params("resnet", 15, 15, 9, 2, 128, seed=2, style="bench")
-        net = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=prm, trunk_arith="bf16x3")
+        net = PolicyValueNet(15, 15, batch_size=64, n_blocks=2, n_filter=128, model_params=prm, trunk_arith=cfg.split("-")[1])
         forced = True
     rec = Recorder(net)
     eng = SelfPlayEngine(rec, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=31337, n_threads=4,
@@ -104,13 +104,13 @@ def test_engine_on_gpu_equals_sequential_oracle_on_recorded_outputs(cfg):
     net.close()
 
 
-@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+@pytest.mark.parametrize("arith", ["f32", "f16x2"])
 def test_full_configuration_engine_equals_sequential_oracle(arith):
     """BASELINE configs[2] EXACTLY -- 15x15, five in a row, n_playout = 400, c_puct 5, temp 1.0, Dirichlet 0.3 / 0.25, the
     10-block / 128-filter residual net (train_mxnet.py:79-91), the forced-opening branch live (game_ai.py:79-111) -- on the
     HIP evaluator, on both trunk arithmetics, against the sequential oracle (mcts_alphaZero.py:141-157, :187-218 and
     game_ai.py:70-139 restated in oracle/mcts_ref.py / selfplay_ref.py, pinned to the reference's own traces on CPU).
-    96 concurrent games = 48-board batches, i.e. the BATCHED trunk kernels (trunk15_wino3_kernel / trunk15_wino3b_kernel;
+    96 concurrent games = 48-board batches, i.e. the BATCHED trunk kernels (trunk15_wino3_kernel / trunk15_wino3h_kernel;
     a board's bits do not depend on the launch shape: tests/test_gpu_net.py).  Game 0 opens freely, game 1 takes the
     forced opening (base seed chosen for that).  Every evaluation those two games consumed is recorded (engine tap) and
     replayed into the oracle: moves, winner and z exact, pi to 1e-12; a 64-row sample of the recorded outputs against the
@@ -161,7 +161,7 @@ def test_full_configuration_engine_equals_sequential_oracle(arith):
     net.close()
 
 
-@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+@pytest.mark.parametrize("arith", ["f32", "f16x2"])
 def test_full_size_properties_1024_games(arith):
     """BASELINE config 3 at full width (1024 concurrent games, 10 blocks, n_playout=400) for a few
     rounds, on both trunk arithmetics: size-independent properties -- one leaf per active game per round,

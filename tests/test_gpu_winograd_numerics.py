@@ -1,7 +1,8 @@
 """Numerics of the fp32 Winograd F(4x4,3x3) trunk kernels under stress, on the GPU: the batched kernel
 (trunk15_wino3_kernel: what the self-play bench runs, forced onto these small batches through apz_test_select_trunk),
-the small-batch kernel (trunk15_wino3s_kernel: what a batch of <= 32 boards gets by default) and, opt-in, the
-3 x bf16 split kernel (trunk15_wino3b_kernel).
+the small-batch kernel (trunk15_wino3s_kernel: what a batch of <= 32 boards gets by default), the 2 x fp16 split kernel
+(trunk15_wino3h_kernel: what a batch of > 32 boards gets by default since round 6) and the 3 x bf16 split kernel
+(trunk15_wino3b_kernel, opt-in).
 
 Winograd's error grows with the magnitude of the transformed operands, so the everyday parity tests
 (tests/test_gpu_net.py: two synthetic initialisations) say little about other weight scales.  Here the full
@@ -85,7 +86,7 @@ CASES = [("base", "random"), ("base", "dense"), ("base", "empty"), ("w4_balanced
 
 # kind (apz_test_select_trunk) -> the kernel that then runs these 6-board batches
 KERNEL_OF = {"wino3-batched": "trunk15_wino3_kernel", "wino3": "trunk15_wino3s_kernel", "ring": "trunk15_ring_kernel",
-             "wino3b": "trunk15_wino3b_kernel"}
+             "wino3b": "trunk15_wino3b_kernel", "wino3h": "trunk15_wino3h_kernel"}
 
 
 def _stress_table(kinds):
@@ -164,3 +165,27 @@ def test_bf16x3_split_trunk_is_fp32_accurate_under_stress():
     for r in rows:
         for key in ("logit_err_rel", "value_err_rel"):
             assert r["wino3b_" + key] <= max(2.0 * r["ring_" + key], 1.25 * r["wino3-batched_" + key], 1e-6), (key, r)
+
+
+def test_f16x2_split_trunk_is_fp32_accurate_under_stress():
+    """trunk15_wino3h_kernel (PolicyValueNet(trunk_arith="f16x2"), the default for batches of more than 32 boards): the same
+    Winograd convolution with every fp32 operand as two fp16 terms on the fp16 matrix pipe (weights times a per-channel
+    power of two, activations as they are).  Same gates as the 3 x bf16 kernel: every row inside the bound the fp32
+    Winograd kernel is held to (1e-4 / 3, relative to the logit scale), and no worse than twice the DIRECT fp32 kernel's own
+    error or 1.25 x the fp32 Winograd kernel's.  The rows whose activations explode (raw x4 weights, variances of 1e-3)
+    leave the fp16 range: there the engine repeats the forward on the exact-fp32 kernel (tests/test_gpu_net.py::
+    test_f16x2_overflow_repeats_the_forward_on_the_exact_kernel) and the row carries that kernel's error.
+    policy_value_net_mxnet.py:77-83 over the 10-block net."""
+    kinds = ("wino3h", "wino3-batched", "ring")
+    rows = _stress_table(kinds)
+    _write_table("r06_winograd_numerics_f16x2.json", kinds, rows)
+
+    def bound(r, key):
+        exploding = r["logit_scale"] > 1e3
+        return max(TOL, 4.0 * r["ring_" + key]) if exploding else TOL
+    bad = [r for r in rows if r["wino3h_logit_err_rel"] > bound(r, "logit_err_rel") or
+           r["wino3h_value_err_rel"] > bound(r, "value_err_rel")]
+    assert not bad, bad
+    for r in rows:
+        for key in ("logit_err_rel", "value_err_rel"):
+            assert r["wino3h_" + key] <= max(2.0 * r["ring_" + key], 1.25 * r["wino3-batched_" + key], 1e-6), (key, r)
