@@ -21,9 +21,18 @@ finished games directly in a steady-state window (continuous refill; minutes).
 `--gpus N` without a torchrun environment starts the N ranks itself (fresh child processes, one per
 GPU, RCCL over 127.0.0.1); under `python -m torch.distributed.run` the ranks are the launcher's.
 
-Extra objects on the JSON line: `roofline` (dominant kernel = trunk 3x3 conv, fp32 matrix pipe;
-`frac` = EXECUTED MFMA flops / time / peak), `roofline_stem` (north_star's HBM target shape
-8192x4x15x15 and the real C_in=9 stem), `cpu_baseline` (sequential CPU oracle port, bounded sample).
+Trunk arithmetic (round 6): batches of more than 32 boards run the 128 -> 128 trunk convolutions on the fp16 matrix pipe
+with every fp32 operand split into two fp16 terms and fp32 accumulation (csrc/trunk15_wino3h.h, `--trunk-arith f16x2`, the
+default "auto"): <= 1e-4 on the logits against the float64 oracle like the exact kernel, different low-order bits.
+`--trunk-arith f32` runs the exact-fp32 kernel; the default line carries its rate as `value_exact_f32`.
+
+`value` is COUNTED inside this run when the `counted` leg succeeds (default command, N = 1: a child process plays with
+continuous refill until every slot has finished a game, then counts finished games over 60 s); `value_derived` keeps the
+rate derived from the timed region.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = trunk 3x3 conv; `frac` = EXECUTED MFMA flops / time / peak
+of the pipe it runs on), `roofline_stem` (north_star's HBM target shape 8192x4x15x15 and the real C_in=9 stem),
+`cpu_baseline` (sequential CPU oracle port, bounded sample).
 """
 import argparse
 import json
@@ -47,9 +56,10 @@ N_PLAYOUT = 400
 N_BLOCKS = 10
 N_FILTER = 128
 GAMES_PER_GPU = 1024
-CALIB = os.path.join(REPO, "profiles", "calibration_r05.json")
+CALIB = next((p_ for p_ in (os.path.join(REPO, "profiles", n_) for n_ in ("calibration_r06.json", "calibration_r05.json"))
+              if os.path.exists(p_)), os.path.join(REPO, "profiles", "calibration_r06.json"))
 FP32_MATRIX_PEAK_TF = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA peak
-BF16_MATRIX_PEAK_TF = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
+BF16_MATRIX_PEAK_TF = 2500.0         # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (~2.5 PFLOP/s)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -61,7 +71,7 @@ def load_mean_plies():
     if os.path.exists(CALIB):
         with open(CALIB) as f:
             c = json.load(f)
-        return float(c["mean_plies_per_game"]), "profiles/calibration_r05.json (%d complete games counted in steady state, MI355X)" % c["games"]
+        return float(c["mean_plies_per_game"]), "profiles/%s (%d complete games counted in steady state, MI355X)" % (os.path.basename(CALIB), c["games"])
     return None, None
 
 
@@ -193,18 +203,40 @@ def stem_roofline(device):
     return out
 
 
-def bf16x3_line(device, threads, G, pipeline, mean_plies, steps=120, warmup=30):
-    """The SAME workload (BASELINE configs[2]) with the trunk on the bf16 matrix pipe at fp32 accuracy: PolicyValueNet(...,
-    trunk_arith="bf16x3") -> csrc/trunk15_wino3b.h (every fp32 operand as three bf16 terms, six bf16 products per fp32
-    product, fp32 accumulation).  An EXTRA object: the line's `value` / `dtype` stay the exact-fp32 kernel's.  Own engine,
-    own timed region (declared: `warmup` untimed steps + the 0.6 s pre-warm, then `steps` timed ones), trunk launches timed
-    by HIP events on the engine stream."""
+ARITH_INFO = {
+    # arith: (dtype text, kernel, executed matrix flops per board PAIR and launch, peak TF, flop text, numerics)
+    "f32": ("f32 (exact fp32 products on the fp32 matrix pipe)", "trunk15_wino3_kernel<RESID>", 2 * 9216 * 2048.0, FP32_MATRIX_PEAK_TF,
+            "9216 v_mfma_f32_16x16x4_f32 x 2048 flop per board",
+            "tests/test_gpu_winograd_numerics.py::test_winograd_trunk_keeps_a_3x_margin_under_stress, profiles/r04_winograd_numerics.json"),
+    "f16x2": ("f32 (split operands on the bf16/fp16 matrix pipe, fp32 accumulate; <=1e-4 vs float64 oracle)", "trunk15_wino3h_kernel<RESID>",
+              36 * 4 * 16 * 2 * 32768.0, BF16_MATRIX_PEAK_TF,
+              "36 positions x 4 groups of 32 output channels x 16 chunks x 2 v_mfma_f32_32x32x16_f16 (32 768 flop) per board pair: "
+              "three fp16 products (+ lo.lo) per fp32 product",
+              "tests/test_gpu_winograd_numerics.py::test_f16x2_split_trunk_is_fp32_accurate_under_stress, "
+              "profiles/r06_winograd_numerics_f16x2.json"),
+    "bf16x3": ("f32-accurate via 3 x bf16 split, fp32 accumulate (PolicyValueNet(trunk_arith='bf16x3'))", "trunk15_wino3b_kernel<RESID>",
+               36 * 4 * 16 * 3 * 32768.0, BF16_MATRIX_PEAK_TF,
+               "36 positions x 4 groups of 32 output channels x 16 chunks x 3 v_mfma_f32_32x32x16_bf16 (32 768 flop) per board pair: "
+               "six bf16 products per fp32 product",
+               "tests/test_gpu_winograd_numerics.py::test_bf16x3_split_trunk_is_fp32_accurate_under_stress, "
+               "profiles/r04_winograd_numerics_bf16x3.json"),
+}
+
+
+def resolve_arith(arith):
+    return "f16x2" if arith == "auto" else arith
+
+
+def arith_line(arith, device, threads, G, pipeline, mean_plies, steps=120, warmup=30):
+    """The SAME workload (BASELINE configs[2]) on another trunk arithmetic (PolicyValueNet(trunk_arith=...)): an EXTRA object
+    beside the line's own `value`.  Own engine, own timed region (declared: `warmup` untimed steps + the 0.6 s pre-warm, then
+    `steps` timed ones), trunk launches timed by HIP events on the engine stream."""
     from alphapig_amd.policy_value_net import PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
     prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
     batch = (G + pipeline - 1) // pipeline
     net = PolicyValueNet(W, H, batch_size=batch, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, device=device,
-                         trunk_arith="bf16x3")
+                         trunk_arith=arith)
     eng = SelfPlayEngine(net, W, H, N_IN_ROW, n_games=G, n_playout=N_PLAYOUT, c_puct=5, temp=1.0, base_seed=20260000,
                          n_threads=threads, pipeline=pipeline)
     eng.run_steps(0)
@@ -226,25 +258,60 @@ def bf16x3_line(device, threads, G, pipeline, mean_plies, steps=120, warmup=30):
     net.set_profiling(False)
     playouts = eng.stats["leaf_evals"] + eng.terminal_playouts() - p0
     leafs = eng.stats["leaf_evals"] - l0
+    overflows = net.trunk_overflows()
     eng.close()
     net.close()
     us = 1e3 * trunk_ms / max(trunk_cnt, 1)
-    # executed bf16 MFMA flops per launch: 36 positions x 4 groups of 32 output channels x 16 chunks x 3 v_mfma_f32_32x32x16_bf16
-    # (32 768 flop) per board PAIR
-    executed = (batch / 2.0) * 36 * 4 * 16 * 3 * 32768.0
+    dtype, kernel, flops_pair, peak, flop_text, numerics = ARITH_INFO[arith]
+    executed = (batch / 2.0) * flops_pair
     tf = executed / (us * 1e-6) / 1e12 if trunk_cnt else None
-    return {"dtype": "f32-accurate via 3 x bf16 split, fp32 accumulate (opt-in: PolicyValueNet(trunk_arith='bf16x3'))",
+    return {"trunk_arith": arith, "dtype": dtype,
             "value": playouts / N_PLAYOUT / mean_plies / dt, "unit": "games/s", "leaf_evals_per_s": leafs / dt,
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
-            "gpu_busy_frac": (fwd_ms * 1e-3 / dt) if fwd_cnt else None,
-            "roofline": {"kernel": "trunk15_wino3b_kernel<RESID>", "bound": "mfma", "achieved": tf, "peak": BF16_MATRIX_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": (tf / BF16_MATRIX_PEAK_TF) if tf else None, "us_per_launch": us,
+            "gpu_busy_frac": (fwd_ms * 1e-3 / dt) if fwd_cnt else None, "forwards_repeated_on_the_exact_kernel": overflows,
+            "roofline": {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": peak,
+                         "unit": "TFLOP/s", "frac": (tf / peak) if tf else None, "us_per_launch": us,
                          "launches": trunk_cnt, "boards_per_launch": batch, "flops_per_launch": executed,
-                         "achieved_basis": "bf16 MFMA flops the kernel executes (six bf16 products per fp32 product) / average launch "
-                                           "duration (HIP events); the same launch does the work of the fp32 kernel's 9.66 GFLOP",
+                         "achieved_basis": "matrix flops the kernel executes (" + flop_text + ") / average launch duration (HIP events)",
                          "fp32_equivalent_tflops": (batch * 9216 * 2048.0 / (us * 1e-6) / 1e12) if trunk_cnt else None},
-            "numerics": "tests/test_gpu_winograd_numerics.py::test_bf16x3_split_trunk_is_fp32_accurate_under_stress, "
-                        "profiles/r04_winograd_numerics_bf16x3.json"}
+            "numerics": numerics}
+
+
+def counted_child(arith, games, pipeline, window_s=60.0, warmup_max_s=260.0, timeout_s=400.0):
+    """Games/s COUNTED inside this run: a fresh child process (`bench.py --count-games`) plays the same configuration with
+    continuous refill until every slot has finished a game (or `warmup_max_s`), then counts finished games over `window_s`.
+    Returns the child's JSON object, or {"error": ...} on a deadline (the line then falls back to the derived value)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--count-games", str(window_s), "--count-warmup-max", str(warmup_max_s),
+           "--games", str(games), "--pipeline", str(pipeline), "--trunk-arith", arith, "--no-extras"]
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, start_new_session=True)
+    except OSError as e:
+        return {"error": "could not start the child: %s" % e}
+    out = ""
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, 9)
+        except OSError:
+            pass
+        try:
+            out, _ = proc.communicate(timeout=10)
+        except Exception:
+            pass
+        return {"error": "deadline of %.0f s passed" % timeout_s, "seconds": time.perf_counter() - t0}
+    for ln in reversed(out.strip().splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                obj = json.loads(ln)
+                obj["seconds_total"] = time.perf_counter() - t0
+                return obj
+            except ValueError:
+                pass
+    return {"error": "no JSON line from the child (exit code %s)" % proc.returncode, "seconds": time.perf_counter() - t0}
 
 
 def train_step_line(device, steps=10, warmup=3):
@@ -538,7 +605,7 @@ def main():
                     help="count finished games over a steady-state window of this many seconds (continuous refill; the "
                          "window opens once every slot has finished a game or after --count-warmup-max seconds)")
     ap.add_argument("--count-warmup-max", type=float, default=420.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem, latency, trunk_bf16x3, train_step, config2 and cpu_baseline")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_stem, latency, trunk_exact_f32, train_step, config2, cpu_baseline and the counted leg")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # child of cpu_baseline()
     ap.add_argument("--exchange-probe", type=int, default=0, metavar="ROWS", help=argparse.SUPPRESS)   # child of exchange_probe_world1()
     ap.add_argument("--config2-worker", action="store_true", help=argparse.SUPPRESS)                   # child of config2_child()
@@ -557,9 +624,14 @@ def main():
                     help="declared UNTIMED GPU-only pre-warm before the W warm-up steps: dummy forwards of empty boards "
                          "(not engine steps) for this many seconds, plus 4 dummy forwards queued right before the closing "
                          "synchronisation of the warm-up so that the timed region starts on a GPU at its running clocks; 0 = off")
-    ap.add_argument("--only-bf16x3", action="store_true",
-                    help="run ONLY the trunk_bf16x3 extra object (the opt-in split kernel's engine run) and print it: the command "
-                         "its rocprofv3 trace is taken of (tools/r04_measure.sh)")
+    ap.add_argument("--trunk-arith", default="auto", choices=["auto", "f32", "f16x2", "bf16x3"],
+                    help="arithmetic of the trunk convolutions on batches of more than 32 boards (PolicyValueNet(trunk_arith=...)); "
+                         "auto = f16x2")
+    ap.add_argument("--only-arith", default=None, choices=["f32", "f16x2", "bf16x3"],
+                    help="run ONLY the extra engine run on this trunk arithmetic and print its object: the command a rocprofv3 "
+                         "trace of one kernel is taken of")
+    ap.add_argument("--no-count", action="store_true", help="skip the counted games/s leg (a child process, ~4 minutes)")
+    ap.add_argument("--count-window", type=float, default=60.0, help="window of the counted leg, seconds")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (gloo, stand-in evaluator from tests/fakenet.py, "
                          "8 games per rank); the JSON line is marked invalid and is NOT a measurement")
@@ -576,12 +648,14 @@ def main():
         dist.init(force=True)                        # a process group of THIS rank alone: RCCL when there is a GPU, else gloo
         print(json.dumps(dist.measure_exchange(args.exchange_probe)))
         return
-    if args.only_bf16x3:
+    if args.only_arith:
         mean_plies, _ = load_mean_plies()
-        obj = bf16x3_line(0, max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), host_cpu_share())), args.games, args.pipeline,
-                          mean_plies, steps=args.steps if args.steps != 1200 else 120, warmup=args.warmup if args.warmup != 100 else 30)
+        obj = arith_line(args.only_arith, 0, max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), host_cpu_share())), args.games,
+                         args.pipeline, mean_plies, steps=args.steps if args.steps != 1200 else 120,
+                         warmup=args.warmup if args.warmup != 100 else 30)
         print(json.dumps(obj))
         return
+    arith = resolve_arith(args.trunk_arith)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:], deadline_s=args.deadline_s, silence_s=args.rank_silence_s,
                            early_exit_grace_s=args.early_exit_grace_s)     # before anything touches the GPU
@@ -637,7 +711,7 @@ def main():
         prm = weights.init_params("resnet", H, W, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
         # one evaluator, one HIP stream; the pipeline groups queue their batches on it back to back
         net = PolicyValueNet(W, H, batch_size=(G + args.pipeline - 1) // args.pipeline, n_blocks=N_BLOCKS,
-                             n_filter=N_FILTER, model_params=prm, device=local)
+                             n_filter=N_FILTER, model_params=prm, device=local, trunk_arith=arith)
     lanes = [net]
     eng = SelfPlayEngine(net, W, H, N_IN_ROW, n_games=G, n_playout=N_PLAYOUT, c_puct=5, temp=1.0, base_seed=20260000,
                          n_threads=threads, pipeline=args.pipeline, index_offset=rank, index_stride=world)
@@ -715,13 +789,15 @@ def main():
                               "leaf_evals_per_s": leafs / dt,
                               "games_per_s_derived": leafs / dt / (N_PLAYOUT * mp) if games else None,
                               "warmup_s": all_done_at, "slots_with_a_finished_game": float(np.mean(eng.slot_games > 0)),
-                              "n_gpus": world, "games_per_gpu_concurrent": G, "host_threads_per_rank": threads}))
+                              "n_gpus": world, "games_per_gpu_concurrent": G, "host_threads_per_rank": threads,
+                              "trunk_arith": arith,
+                              "forwards_repeated_on_the_exact_kernel": sum(ln.trunk_overflows() for ln in lanes)}))
         eng.close()
         for ln in lanes:
             ln.close()
         return
     if mean_plies is None:
-        raise SystemExit("profiles/calibration_r05.json missing: run `python bench.py --count-games 240` once")
+        raise SystemExit("profiles/calibration_r0x.json missing: run `python bench.py --count-games 240` once")
 
     import gc
     gc.collect()
@@ -811,11 +887,11 @@ def main():
 
     games_per_s = playouts / N_PLAYOUT / mean_plies / dt
     st_ms = sorted(1e3 * x for x in getattr(eng, "step_times", []))
-    tk = "wino3"                                    # the product's trunk kernel (csrc/trunk15_wino3.h)
+    tk = {"f32": "wino3", "f16x2": "wino3h", "bf16x3": "wino3b"}[arith]      # the trunk kernel of this run's arithmetic
     # HBM / fabric traffic per launch of the dominant kernel: PMC passes of rocprofv3 on this same command
     # (cannot be collected from inside the process), committed under profiles/
     traffic, traffic_src = None, None
-    for tname in ("r05_trunk_traffic.json", "r04_trunk_traffic.json", "r03_trunk_traffic.json", "r02_trunk_traffic.json"):
+    for tname in ("r06_trunk_traffic.json", "r05_trunk_traffic.json", "r04_trunk_traffic.json", "r03_trunk_traffic.json", "r02_trunk_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -824,19 +900,27 @@ def main():
                 traffic, traffic_src = tj["traffic_bytes_per_launch"]["mean"], "profiles/" + tname
                 break
     trunk_avg_ms = trunk_ms / max(trunk_cnt, 1)
-    kernel_name = "trunk15_wino3_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, single pass: two boards x 64 output channels per work item)"
-    # MFMA flops the kernel really issues: 36 positions x 8 channel tiles x 32 k-steps of v_mfma_f32_16x16x4_f32
-    # (2048 flop) per board.
-    # `achieved` / `frac` are on THIS basis (a fraction of the matrix pipe's peak, <= 1); the rate of the layer's
-    # definition (direct-convolution flops / time, which Winograd makes exceed the peak) is kept beside it.
-    executed = batch * 9216 * 2048.0
+    dtype_text, kshort, flops_pair, peak_tf, flop_text, numerics_src = ARITH_INFO[arith]
+    kernel_name = {"f32": "trunk15_wino3_kernel<RESID> (fused F(4x4,3x3) Winograd on fp32 MFMA, single pass: two boards x 64 output channels per work item)",
+                   "f16x2": "trunk15_wino3h_kernel<RESID> (fused F(4x4,3x3) Winograd, every fp32 operand as two fp16 terms on the fp16 matrix pipe, "
+                            "fp32 accumulation: two boards x 64 output channels per work item)",
+                   "bf16x3": "trunk15_wino3b_kernel<RESID> (fused F(4x4,3x3) Winograd, three bf16 terms per operand)"}[arith]
+    # Matrix flops the kernel really issues (ARITH_INFO).  `achieved` / `frac` are on THIS basis (a fraction of the peak of the
+    # pipe the kernel runs on, <= 1); the rate of the layer's definition (direct-convolution flops / time) and the fp32
+    # products per second (what the exact kernel's 9.66 GFLOP per launch would be) are kept beside it.
+    executed = (batch / 2.0) * flops_pair
     executed_tf = executed / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
     direct_tf = trunk_flops(batch) / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
+    fp32_equiv_tf = batch * 9216 * 2048.0 / (trunk_avg_ms * 1e-3) / 1e12 if trunk_cnt else None
+    # algorithmic bytes of one launch (direct-convolution minimum): input + output planes (+ residual on
+    # every second launch) in the rows16 layout + the layer's weights once
+    alg_bytes = batch * N_FILTER * 960.0 * 2.5 + 9 * N_FILTER * N_FILTER * 4.0
     arena_gb = eng.pool.arena_bytes() / 1e9 if hasattr(eng.pool, "arena_bytes") else None
     line = {
         "metric": "self-play games/sec (15x15, n_playout=400)", "value": games_per_s, "unit": "games/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_text, "data": "synthetic",
+        "trunk_arith": arith, "forwards_repeated_on_the_exact_kernel": sum(ln.trunk_overflows() for ln in lanes) if not args.plumbing_test else 0,
         "config": {"workload": "BASELINE configs[2]: 15x15, 5-in-row, n_playout=400, c_puct=5, temp=1.0, "
                                "10-block/128-filter residual net, %d concurrent games per GPU" % G,
                    "games_per_gpu": G, "leaf_batch": batch, "pipeline": args.pipeline, "host_threads": threads,
@@ -854,10 +938,10 @@ def main():
                     ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "single process"),
         "leaf_evals_per_s": leafs / dt,
         "playouts_per_s": playouts / dt,
-        "value_basis": "derived: playouts of the timed region / n_playout / mean plies per game (config.mean_plies_per_game); the same "
-                       "quantity COUNTED over a steady-state window is in counted_steady_state (bench.py --count-games)",
+        "value_basis": "derived: playouts of the timed region / n_playout / mean plies per game (config.mean_plies_per_game)",
+        "value_derived": games_per_s,
         "counted_steady_state": dict(load_counted() or {}, note="COMMITTED builder-run measurement (bench.py --count-games), echoed "
-                                     "for context; NOT measured by this run"),
+                                     "for context; NOT measured by this run (this run's own count: `counted`)"),
         "host_tree_s": eng.timers["host_s"] - host0, "evaluator_s": eng.timers["eval_s"] - eval0, "wall_s": dt,
         # GPU time of the timed region: every forward (stem .. value head, kernels back to back) bracketed by one HIP
         # event pair on the engine stream; busy fraction = their sum / wall clock of the timed region (rank 0)
@@ -868,11 +952,19 @@ def main():
         "step_ms": ({"median": st_ms[len(st_ms) // 2], "max": st_ms[-1], "min": st_ms[0]} if st_ms else None),
         "prewarm": prewarm,
         "roofline": {"kernel": kernel_name + ": trunk 128->128 3x3 conv + folded BN (+residual) + ReLU; 20 launches per forward",
-                     "bound": "mfma", "achieved": executed_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": (executed_tf / FP32_MATRIX_PEAK_TF) if executed_tf else None,
-                     "achieved_basis": "MFMA flops the kernel executes (9216 v_mfma_f32_16x16x4_f32 x 2048 flop per board) / "
+                     "bound": "mfma", "achieved": executed_tf, "peak": peak_tf, "unit": "TFLOP/s",
+                     "frac": (executed_tf / peak_tf) if executed_tf else None,
+                     "achieved_basis": "matrix flops the kernel executes (" + flop_text + ") / "
                                        "average launch duration (HIP events on the engine stream inside the timed region)",
                      "flops_per_launch": executed,
+                     "fp32_products_equivalent": {"tflops": fp32_equiv_tf, "frac_of_fp32_matrix_peak": (fp32_equiv_tf / FP32_MATRIX_PEAK_TF) if fp32_equiv_tf else None,
+                                                  "note": "the exact-fp32 kernel's 9.66 GFLOP per 512 boards / this kernel's time: what the "
+                                                          "fp32 pipe would have to sustain to match it (peak 157.3)"},
+                     "hbm_view": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_gbs": (alg_bytes / (trunk_avg_ms * 1e-3) / 1e9) if trunk_cnt else None,
+                                  "peak_gbs": HBM_PEAK_GBS, "frac": (alg_bytes / (trunk_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if trunk_cnt else None,
+                                  "note": "direct-convolution minimum bytes (input + output, residual on every second launch, weights once) / "
+                                          "the same time: neither the matrix pipe nor HBM bounds this kernel -- DESIGN section 9"},
+                     "numerics": numerics_src,
                      "direct_conv_equivalent": {"tflops": direct_tf, "flops_per_launch": trunk_flops(batch),
                                                 "note": "SURVEY 8(d) algorithmic flops of the layer (2*9*128*128*225 per board) / the "
                                                         "same time; exceeds the peak because Winograd executes 3.5x fewer flops"},
@@ -909,13 +1001,29 @@ def main():
                                     "here); this is the committed N = 1 measurement, not part of this run")
     if not args.no_extras and world == 1 and not args.plumbing_test:
         for key, fn in (("roofline_stem", lambda: stem_roofline(local)), ("latency", lambda: latency_probe(local)),
-                        ("trunk_bf16x3", lambda: bf16x3_line(local, threads, G, args.pipeline, mean_plies)),
+                        ("trunk_exact_f32" if arith != "f32" else "trunk_f16x2",
+                         lambda: arith_line("f32" if arith != "f32" else "f16x2", local, threads, G, args.pipeline, mean_plies)),
                         ("train_step", lambda: train_step_line(local)), ("config2", lambda: config2_child()),
                         ("cpu_baseline", lambda: cpu_baseline(mean_plies, cores=max(1, min(16, ncpu))))):
             heartbeat("extra: %s" % key)
             line[key] = fn()
         heartbeat("extra: exchange probe (child process, one-rank process group)")
-        line["exchange"] = exchange_probe_world1(exch_rows)     # last: bounded, and nothing else depends on it
+        line["exchange"] = exchange_probe_world1(exch_rows)     # bounded, and nothing else depends on it
+        if arith != "f32" and isinstance(line.get("trunk_exact_f32"), dict):
+            line["value_exact_f32"] = line["trunk_exact_f32"].get("value")      # the same workload on the exact-fp32 trunk kernel
+        if not args.no_count:
+            heartbeat("counted leg: child process, continuous refill until every slot has finished a game, then a %.0f s window" % args.count_window)
+            cnt = counted_child(arith, G, args.pipeline, window_s=args.count_window)
+            line["counted"] = cnt
+            if cnt.get("games_per_s_counted") and cnt.get("slots_with_a_finished_game", 0) >= 0.999:
+                line["value"] = cnt["games_per_s_counted"]
+                line["value_basis"] = ("COUNTED in this run: finished games / seconds over a %.0f s steady-state window of a child process "
+                                       "of this command (continuous refill, opened once every slot had finished a game); mean plies per "
+                                       "game of the window in counted.mean_plies_per_game; the rate derived from the timed region is "
+                                       "value_derived" % cnt.get("window_s", args.count_window))
+                line["counted_steady_state"]["note"] = "COMMITTED builder-run measurement, echoed for context; this run's own count is in `counted`"
+            else:
+                line["value_basis"] += " -- the counted leg did not complete (%s): value stays derived" % (cnt.get("error") or "window opened before every slot had finished a game")
         heartbeat("extras done")
     print(json.dumps(line))
 
