@@ -207,18 +207,28 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
     static constexpr int RING = APZH_RING;
     static_assert(RING == 6 || RING == 9 || RING == 18, "ring slots must tile two chunks");
     f16x8 af[RING];
-    auto unit_load = [&](int t, int c, int p9, int slot) {
-        // (c, p9) may run past the end of the item: carry into the next item; past the last item: reload the last unit
-        if (p9 >= 9) { p9 -= 9; c += 1; }
-        if (c >= T::NCHUNK) { c -= T::NCHUNK; t += 1; }
-        if (t >= nitems) { t = nitems - 1; c = T::NCHUNK - 1; p9 = 8; }
+    // byte offset of unit (t, c, 0).  The units of an item are contiguous (144 x 1 KB per wave), so a chunk body needs two
+    // uniform bases -- this chunk's and the next one's (which may belong to the next item) -- and every load is base +
+    // (p9 / 4) * 4096 as the scalar offset + (p9 % 4) * 1024 as the instruction's immediate: ~6 scalar instructions per chunk
+    // instead of five per load.  Behind the last chunk of the last item the "next" base just runs on (unused data; the buffer
+    // descriptor bounds it).
+    auto unit_base = [&](int t, int c) {
         const int cog = 2 * item_half(t) + cc;
+        return (unsigned)(((cog * 4 + blk) * T::NCHUNK + c) * 9) * T::UNIT;
+    };
+    unsigned ub_cur = 0, ub_nxt = 0;                  // bases of the chunk being multiplied and of the one after it
+    auto unit_load_at = [&](unsigned base, int p9, int slot) {
 #if defined(APZH_ABL_W) && APZH_ABL_W == 2   /* measurement build: every weight load reads the same (L1-resident) unit */
-        const unsigned so = (unsigned)(cog * 4 + blk) * T::UNIT + 0u * (unsigned)(c + p9);
+        af[slot] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_u, a_vo, (unsigned)(cc * 4 + blk) * T::UNIT + 0u * (base + p9), 0));
 #else
-        const unsigned so = (unsigned)(((cog * 4 + blk) * T::NCHUNK + c) * 9 + p9) * T::UNIT;
+        af[slot] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_u, a_vo + (unsigned)(p9 & 3) * T::UNIT,
+                                                                                  base + (unsigned)(p9 >> 2) * 4u * T::UNIT, 0));
 #endif
-        af[slot] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_u, a_vo, so, 0));
+    };
+    // unit p9 (0 .. 8 + RING - 1) counted from the start of the current chunk
+    auto unit_load = [&](int p9, int slot) {
+        if (p9 < 9) unit_load_at(ub_cur, p9, slot);
+        else unit_load_at(ub_nxt, p9 - 9, slot);
     };
 
     auto af_keep = [&](int s_) { asm volatile("" ::"v"(af[s_])); };   // (measurement builds)
@@ -342,9 +352,10 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
 
         // zero halo rows of both raw buffers (the DMA never touches them), once
         for (int i = tid * 4; i < 2 * T::RAW_FLOATS; i += 2048) *reinterpret_cast<f32x4*>(&lds[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
-        // the first RING - 1 weight units
+        // the first RING - 1 weight units (the first chunk body takes its base from ub_nxt)
+        ub_cur = ub_nxt = unit_base(0, 0);
 #pragma unroll
-        for (int u = 0; u < RING - 1; u++) unit_load(0, 0, u, u);
+        for (int u = 0; u < RING - 1; u++) unit_load(u, u);
         __syncthreads();
         raw_dma(0, 0, 0);                              // the first item's first two chunks (later items: from the epilogue before)
         raw_dma(0, 1, 1);
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
 #if APZH_ABL_W == 1
 #define APZH_ULOAD(k)
 #else
-#define APZH_ULOAD(k) unit_load(t, c, (k) + RING - 1, (par * 9 + (k) + RING - 1) % RING);
+#define APZH_ULOAD(k) unit_load((k) + RING - 1, (par * 9 + (k) + RING - 1) % RING);
 #endif
 #ifndef APZH_PRIO
 #define APZH_PRIO 1
@@ -437,6 +448,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 constexpr int par = decltype(PAR)::value;
                 if (!APZH_ABL_S) __syncthreads();     // V[par] and raw[1 - par] complete; V[1 - par] and raw[par] free
                 APZH_STAMP(1)
+                ub_cur = ub_nxt;                      // (chunk 0 of item 0: set in front of the loop)
+                ub_nxt = c + 1 < T::NCHUNK ? ub_cur + 9u * T::UNIT : (t + 1 < nitems ? unit_base(t + 1, 0) : ub_cur + 9u * T::UNIT);
                 const char* vp = vbase + par * T::V_BYTES;
                 // per-lane fragment offset rebuilt from an opaque copy of the lane id (kept live across the kernel it is
                 // what hipcc spills, and every scratch reload is followed by vmcnt(0): a full drain of the weight ring)
