@@ -232,16 +232,28 @@ def all_gather_tuples(codes, pis, zs, consumer=None, timing=False):
     t_counts = mark()
     # one byte buffer per rank, three contiguous sections padded to tmax rows each: [pi (f32) | z (f32) | codes] -- the
     # float sections first (4-byte aligned whatever S is); packing and unpacking are plain block copies (a row-interleaved
-    # layout cost 0.86 s to unpack per 80 MB on the consumer)
+    # layout cost 0.86 s to unpack per 80 MB on the consumer).  The padding is never read (every rank unpacks counts[r]
+    # rows), so nothing is zero-filled; on a GPU the rows are packed straight into a reused PINNED staging buffer (round 5:
+    # a fresh np.zeros of the whole buffer + a copy from pageable memory were 16 of the call's 36 ms per 80 MB).
     row = S + 4 * HW + 4
     o_z, o_c = tmax * 4 * HW, tmax * (4 * HW + 4)
-    buf = np.zeros(tmax * row, dtype=np.uint8)
+    nbytes = tmax * row
+    cuda = dev.type == "cuda"
+    if cuda:
+        send_host = _staging("send", nbytes, torch)
+        buf = send_host.numpy()
+    else:
+        buf = np.empty(nbytes, dtype=np.uint8)
     buf[:T * 4 * HW] = pis.reshape(-1).view(np.uint8)
     buf[o_z:o_z + 4 * T] = zs.view(np.uint8)
     buf[o_c:o_c + T * S] = codes.reshape(-1)
     t_pack = mark()
-    send = torch.from_numpy(buf).to(dev)
-    recv = torch.empty(world * tmax * row, dtype=torch.uint8, device=dev)
+    if cuda:
+        send = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        send.copy_(send_host[:nbytes], non_blocking=True)
+    else:
+        send = torch.from_numpy(buf)
+    recv = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
     t_h2d = mark()
     dist.all_gather_into_tensor(recv, send)
     t_coll = mark()
@@ -249,17 +261,49 @@ def all_gather_tuples(codes, pis, zs, consumer=None, timing=False):
         last_gather_stats = {"rows_per_rank": [int(c) for c in counts], "row_bytes": int(row),
                              "bytes_sent_per_rank": int(tmax) * int(row), "bytes_gathered": int(world) * int(tmax) * int(row),
                              "counts_ms": 1e3 * (t_counts - t_start), "pack_ms": 1e3 * (t_pack - t_counts),
-                             "h2d_ms": 1e3 * (t_h2d - t_pack), "collective_ms": 1e3 * (t_coll - t_h2d), "d2h_unpack_ms": 0.0,
-                             "backend": str(dist.get_backend()), "world_size": int(world)}
+                             "h2d_ms": 1e3 * (t_h2d - t_pack), "collective_ms": 1e3 * (t_coll - t_h2d), "d2h_ms": 0.0,
+                             "unpack_ms": 0.0, "backend": str(dist.get_backend()), "world_size": int(world),
+                             "consumer": None if consumer is None else int(consumer)}
     if consumer is not None and dist.get_rank() != int(consumer):
+        if cuda:
+            torch.cuda.current_stream(dev).synchronize()      # the staging buffer is reused by the next call
         return codes[:0], pis[:0], zs[:0]
-    out = recv.cpu().numpy().reshape(world, tmax * row)
-    g_pis = np.concatenate([out[r, :counts[r] * 4 * HW] for r in range(world)]).view(np.float32).reshape(-1, HW)
-    g_zs = np.concatenate([out[r, o_z:o_z + 4 * counts[r]] for r in range(world)]).view(np.float32).reshape(-1)
-    g_codes = np.concatenate([out[r, o_c:o_c + counts[r] * S] for r in range(world)]).reshape(-1, S)
+    if cuda:
+        recv_host = _staging("recv", world * nbytes, torch)
+        recv_host[:world * nbytes].copy_(recv, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        out = recv_host.numpy()[:world * nbytes].reshape(world, nbytes)
+    else:
+        out = recv.numpy().reshape(world, nbytes)
+    t_d2h = time.perf_counter()
+    # one copy out of the (reused) staging buffer into the arrays the caller keeps
+    total = int(counts.sum())
+    g_pis = np.empty((total, HW), np.float32)
+    g_zs = np.empty(total, np.float32)
+    g_codes = np.empty((total, S), np.uint8)
+    at = 0
+    for r in range(world):
+        c = int(counts[r])
+        if c:
+            g_pis[at:at + c].reshape(-1).view(np.uint8)[:] = out[r, :c * 4 * HW]
+            g_zs[at:at + c].view(np.uint8)[:] = out[r, o_z:o_z + 4 * c]
+            g_codes[at:at + c].reshape(-1)[:] = out[r, o_c:o_c + c * S]
+            at += c
     if timing:
-        last_gather_stats["d2h_unpack_ms"] = 1e3 * (time.perf_counter() - t_coll)
+        last_gather_stats["d2h_ms"] = 1e3 * (t_d2h - t_coll)
+        last_gather_stats["unpack_ms"] = 1e3 * (time.perf_counter() - t_d2h)
     return g_codes, g_pis, g_zs
+
+
+_STAGING = {}
+
+
+def _staging(name, nbytes, torch):
+    """A pinned host buffer of at least `nbytes` bytes, kept between calls (grown by half when too small)."""
+    t = _STAGING.get(name)
+    if t is None or t.numel() < nbytes:
+        _STAGING[name] = t = torch.empty(int(nbytes * 1.5) + 4096, dtype=torch.uint8).pin_memory()
+    return t
 
 
 def synthetic_round_payload(rows, code_stride=240, hw=225, seed=0):
@@ -275,11 +319,13 @@ def synthetic_round_payload(rows, code_stride=240, hw=225, seed=0):
     return codes, pis, zs
 
 
-def measure_exchange(rows, code_stride=240, hw=225, repeats=3, seed=0, consumer=None):
+def measure_exchange(rows, code_stride=240, hw=225, repeats=3, seed=0, consumer=None, both=True):
     """Time `all_gather_tuples` on a synthetic full-round payload of `rows` rows per rank (this rank's rows are seeded
     by its rank): one untimed call, then `repeats` timed ones between barriers; -> dict for the bench line (whole-call
-    wall time as the MAX over ranks, the collective alone, bytes, GB/s), or None without a process group.  The gathered
-    rows are checked against what every rank must have sent (regenerated from the seeds)."""
+    wall time as the MAX over ranks, the collective alone, bytes, GB/s, every phase of rank 0's call), or None without a
+    process group.  The gathered rows are checked against what every rank must have sent (regenerated from the seeds).
+    both = True: measured twice -- every rank unpacks everything (consumer=None: the top-level numbers) and the training
+    pipeline's mode, only rank 0 unpacks (`pipeline_mode`, consumer=0: pipeline.TrainPipeline._run_async)."""
     import time
     if not _ACTIVE:
         return None
@@ -287,32 +333,46 @@ def measure_exchange(rows, code_stride=240, hw=225, repeats=3, seed=0, consumer=
     if not dist.is_initialized():
         return None
     rank, world = dist.get_rank(), dist.get_world_size()
+    if rows <= 0:
+        return {"what": "no rows to exchange", "rows_per_rank": 0, "ranks_seen": int(round(all_reduce_sum(1))), "payload_verified": True}
     codes, pis, zs = synthetic_round_payload(rows, code_stride, hw, seed + rank)
-    wall, coll, stats = [], [], None
-    for it in range(repeats + 1):
-        barrier()
-        t0 = time.perf_counter()
-        g = all_gather_tuples(codes, pis, zs, consumer=consumer, timing=True)
-        dt = all_reduce_max(time.perf_counter() - t0)
-        if it:
-            wall.append(dt)
-            coll.append(all_reduce_max(last_gather_stats["collective_ms"]))
-            stats = dict(last_gather_stats)
-    ok = True
-    if consumer is None or rank == consumer:
-        ok = g[0].shape[0] == rows * world
-        for r in range(world) if ok else ():
-            c, p, z = (codes, pis, zs) if r == rank else synthetic_round_payload(rows, code_stride, hw, seed + r)
-            sl = slice(r * rows, (r + 1) * rows)
-            ok = ok and np.array_equal(g[0][sl], c) and np.array_equal(g[1][sl], p) and np.array_equal(g[2][sl], z)
-    ok = all_reduce_sum(0.0 if ok else 1.0) == 0.0
-    ms, cms = 1e3 * float(np.median(wall)), float(np.median(coll))
-    return {"what": "one dist.all_gather_tuples of a full round's (codes | pi | z) rows per rank, synthetic rows, outside the "
-                    "timed region; every rank's rows checked on arrival",
-            "rows_per_rank": int(rows), "row_bytes": stats["row_bytes"], "bytes_sent_per_rank": stats["bytes_sent_per_rank"],
-            "bytes_gathered_per_rank": stats["bytes_gathered"], "ms": ms, "collective_ms": cms,
-            "GB_per_s_collective": stats["bytes_gathered"] / (cms * 1e-3) / 1e9 if cms > 0 else None,
-            "GB_per_s_whole_call": stats["bytes_gathered"] / (ms * 1e-3) / 1e9 if ms > 0 else None,
-            "phases_ms_rank0": {k: stats[k] for k in ("counts_ms", "pack_ms", "h2d_ms", "collective_ms", "d2h_unpack_ms")},
-            "backend": stats["backend"], "ranks_seen": int(round(all_reduce_sum(1))), "repeats": int(repeats),
-            "payload_verified": bool(ok)}
+
+    def one_mode(cons):
+        wall, coll, stats, g = [], [], None, None
+        for it in range(repeats + 1):
+            barrier()
+            t0 = time.perf_counter()
+            g = all_gather_tuples(codes, pis, zs, consumer=cons, timing=True)
+            dt_local = time.perf_counter() - t0
+            dt = all_reduce_max(dt_local)
+            if it:
+                wall.append(dt)
+                coll.append(all_reduce_max(last_gather_stats["collective_ms"]))
+                stats = dict(last_gather_stats, whole_call_ms_this_rank=1e3 * dt_local)
+        ok = True
+        if cons is None or rank == cons:
+            ok = g[0].shape[0] == rows * world
+            for r in range(world) if ok else ():
+                c, p, z = (codes, pis, zs) if r == rank else synthetic_round_payload(rows, code_stride, hw, seed + r)
+                sl = slice(r * rows, (r + 1) * rows)
+                ok = ok and np.array_equal(g[0][sl], c) and np.array_equal(g[1][sl], p) and np.array_equal(g[2][sl], z)
+        ok = all_reduce_sum(0.0 if ok else 1.0) == 0.0
+        ms, cms = 1e3 * float(np.median(wall)), float(np.median(coll))
+        phases = {k: stats[k] for k in ("counts_ms", "pack_ms", "h2d_ms", "collective_ms", "d2h_ms", "unpack_ms")}
+        phases["unattributed_ms"] = stats["whole_call_ms_this_rank"] - sum(phases.values())
+        return {"ms": ms, "collective_ms": cms,
+                "GB_per_s_collective": stats["bytes_gathered"] / (cms * 1e-3) / 1e9 if cms > 0 else None,
+                "GB_per_s_whole_call": stats["bytes_gathered"] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                "phases_ms_rank0": phases, "payload_verified": bool(ok)}, stats
+    top, stats = one_mode(consumer)
+    res = {"what": "one dist.all_gather_tuples of a full round's (codes | pi | z) rows per rank, synthetic rows, outside the "
+                   "timed region; every rank's rows checked on arrival",
+           "rows_per_rank": int(rows), "row_bytes": stats["row_bytes"], "bytes_sent_per_rank": stats["bytes_sent_per_rank"],
+           "bytes_gathered_per_rank": stats["bytes_gathered"], "consumer": consumer}
+    res.update(top)
+    if both and consumer is None:
+        res["pipeline_mode"] = dict(one_mode(0)[0], consumer=0,
+                                    what="the training pipeline's call: only rank 0 copies the gathered rows to the host and unpacks them")
+        res["payload_verified"] = bool(res["payload_verified"] and res["pipeline_mode"]["payload_verified"])
+    res.update(backend=stats["backend"], ranks_seen=int(round(all_reduce_sum(1))), repeats=int(repeats))
+    return res

@@ -178,6 +178,7 @@ class TrainPipeline(object):
         self._fresh = None
         self._lock = threading.Lock()
         self._trainer_error = None
+        self._sgf_done = threading.Event()     # asynchronous schedule: set by rank 0's trainer thread behind the SGF bootstrap
         self._last = (0.0, 0.0, 0.0)
 
     # ---- data collection -----------------------------------------------------------------
@@ -234,10 +235,13 @@ class TrainPipeline(object):
         net = self.policy_value_net if kl_net is None else kl_net
         trainer = self._trainer() if trainer is None else trainer
         t_before = getattr(trainer, "t", 0)
+        mon = {}
         loss, entropy, kl, self.lr_multiplier = policy_update(trainer, mini, self.learn_rate, self.lr_multiplier,
-                                                              self.epochs, self.kl_targ, evaluator=_KeepTrainer(net))
+                                                              self.epochs, self.kl_targ, evaluator=_KeepTrainer(net), monitors=mon)
         self._train_steps += max(0, getattr(trainer, "t", 0) - t_before)
-        _logger.info("kl:%.4f lr_multiplier:%.3f loss:%.4f entropy:%.4f", kl, self.lr_multiplier, loss, entropy)
+        self.last_monitors = mon                          # train_mxnet.py:222-239: the value head's explained variance
+        _logger.info("kl:%.4f lr:%.1e lr_multiplier:%.3f loss:%.4f entropy:%.4f explained_var_old:%.3f explained_var_new:%.3f",
+                     kl, mon["learn_rate"], self.lr_multiplier, loss, entropy, mon["explained_var_old"], mon["explained_var_new"])
         return loss, entropy, kl
 
     def _exchange_update(self, rec):
@@ -375,12 +379,18 @@ class TrainPipeline(object):
                 busy_until = 0.0
                 stop = False
                 # SGF bootstrap (train_mxnet.py:270-271: the first batches replay game records instead of searching):
-                # game batches 0 ... n_sgf - 1, one record + one policy_update each, here on the trainer thread while the
-                # ranks already self-play; what they finish meanwhile waits in the queue and joins the buffer afterwards
+                # game batches 0 ... n_sgf - 1, one record + one policy_update each, here on the trainer thread.  Self-play
+                # starts from the net these batches trained (train_mxnet.py:268-272): every rank HOLDS in _run_async until
+                # `_sgf_done` is set, so no game of the untrained net enters the buffer or counts toward the budget.
                 n_sgf = self._sgf_phase_batches()
                 for i in range(n_sgf):
+                    before = len(self.data_buffer)
                     self.collect_selfplay_data(i)
-                    rec = {"batch": i + 1, "sgf": True, "episode_len": self.episode_len, "buffer": len(self.data_buffer)}
+                    # (the record's own length: self.episode_len belongs to the main thread once self-play runs)
+                    ep_len = (len(self.data_buffer) - before) // 8 if len(self.data_buffer) > before else 0
+                    rec = {"batch": i + 1, "sgf": True, "episode_len": ep_len or self.episode_len, "buffer": len(self.data_buffer)}
+                    if len(self.data_buffer) == before:
+                        rec["skipped"] = True                            # an unreadable record: nothing joined the buffer
                     if len(self.data_buffer) > self.batch_size:
                         t0 = time.time()
                         loss, entropy, kl = self.policy_update(trainer, kl_net)
@@ -394,6 +404,7 @@ class TrainPipeline(object):
                     self._schedule_after_batch(i, rec, kl_net)
                     with self._lock:
                         self.trainer_history.append(rec)
+                self._sgf_done.set()
                 batches_done = n_sgf
                 while not stop:
                     items = [self._train_q.get()]
@@ -436,8 +447,9 @@ class TrainPipeline(object):
                     self._schedule_after_batch(batches_done - 1, rec, kl_net, first=first)
                     with self._lock:
                         self.trainer_history.append(rec)
-        except BaseException as e:          # surfaces in the main thread at the next round
+        except BaseException as e:          # surfaces in the main thread at the next round (or in the bootstrap hold)
             self._trainer_error = e
+            self._sgf_done.set()
 
     def _sgf_phase_batches(self):
         """How many leading game batches replay SGF records (0 without records), never more than game_batch_num."""
@@ -477,12 +489,31 @@ class TrainPipeline(object):
             self._train_q = queue.Queue()
             self._trainer_thread = threading.Thread(target=self._trainer_main, name="apz-trainer", daemon=True)
             self._trainer_thread.start()
+        # The SGF bootstrap first (train_mxnet.py:268-272: self-play starts from the net the game records trained): every
+        # rank holds here until rank 0's trainer thread reports the bootstrap batches done.  One short header round trip per
+        # interval: no rank sits in a single collective for long, and a trainer failure travels with it.
+        bootstrap = self._sgf_phase_batches() > 0
+        while True:
+            flags = [1.0, 0.0]
+            if lead:
+                ready = self._sgf_done.wait(timeout=0.5)
+                flags = [1.0 if ready else 0.0, 1.0 if self._trainer_error is not None else 0.0]
+            if self.distributed:
+                flags = dist.broadcast_floats(flags, src=0)
+            if flags[1] != 0.0:
+                raise RuntimeError("the trainer thread died on rank 0") from (self._trainer_error if lead else None)
+            if flags[0] != 0.0:
+                break
         rnd = 0
         stop = False
+        draining = False            # the budget is reached and rank 0's trainer works off its queue: rounds without play
         while not stop:
             rnd += 1
-            self._play_round()
-            eps = self.engine.finished[:]
+            if draining:
+                time.sleep(0.2)     # (short header rounds instead of one long wait inside a collective: dist's watchdog)
+            elif not (bootstrap and rnd == 1):      # round 1 after a bootstrap only installs the bootstrap's weights
+                self._play_round()
+            eps = [] if draining else self.engine.finished[:]
             del self.engine.finished[:len(eps)]
             self._taken += len(eps)
             if eps:
@@ -495,7 +526,7 @@ class TrainPipeline(object):
                 pis = np.zeros((0, self.board_width * self.board_height), np.float32)
                 zs = np.zeros(0, np.float32)
             n_games = len(eps)
-            if self.distributed:
+            if self.distributed and not draining:
                 n_games = int(round(dist.all_reduce_sum(len(eps))))
                 codes, pis, zs = dist.all_gather_tuples(codes, pis, zs, consumer=0)      # THE exchange of the round
             self.last_gathered = n_games
@@ -507,14 +538,17 @@ class TrainPipeline(object):
                 if len(zs) and self._trainer_error is None:
                     self._train_q.put((codes, pis, zs, n_games))
                 done = self._games_collected >= target_games
-                if done and self._trainer_error is None:        # drain: the only time anybody waits for the trainer
-                    self._train_q.put(None)
-                    self._trainer_thread.join()
+                state = 0.0
+                if done and self._trainer_error is None:
+                    if not draining:
+                        self._train_q.put(None)              # drain: the trainer finishes its queue and leaves
+                    self._trainer_thread.join(timeout=0.0 if self.distributed else None)
+                    state = 2.0 if self._trainer_thread.is_alive() else 1.0
                 failed = self._trainer_error is not None        # travels in the header: every rank leaves the loop together
                 with self._lock:
                     fresh, self._fresh = self._fresh, None
                     loss, entropy, kl = self._last
-                    head = [1.0 if done else 0.0, float(fresh[0]) if fresh else float(self.weights_version),
+                    head = [state, float(fresh[0]) if fresh else float(self.weights_version),
                             float(self.updates_done), loss, entropy, kl, self.lr_multiplier, float(self._games_collected),
                             float(self.updates_skipped)]
                 if failed:
@@ -533,6 +567,7 @@ class TrainPipeline(object):
             self.round_log.append((time.time(), int(self.engine.stats["leaf_evals"])))
             self.history.append(rec)
             stop = head[0] == 1.0
+            draining = head[0] == 2.0
         return self.history
 
     def close(self):

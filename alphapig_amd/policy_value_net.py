@@ -367,7 +367,8 @@ class LanedEvaluator(object):
             raise ValueError("at least one lane")
         self.lanes = list(lanes)
         first = self.lanes[0]
-        self.n_slots = max(first.n_slots, len(self.lanes))
+        # every lane contributes its own slots: slot s -> lane s % k, lane slot s // k
+        self.n_slots = first.n_slots * len(self.lanes)
         self.batchsize, self.hw, self.code_stride = first.batchsize, first.hw, first.code_stride
         for ln in self.lanes[1:]:
             if (ln.batchsize, ln.hw, ln.code_stride) != (self.batchsize, self.hw, self.code_stride):
@@ -402,9 +403,24 @@ class LanedEvaluator(object):
     def sample_moves(self, *a, **kw):
         return self.lanes[0].sample_moves(*a, **kw)
 
+    def __getattr__(self, name):
+        # the rest of the evaluator interface (policy_value, policy_value_fn, save_model, net_kind, _n_blocks, _n_filter,
+        # _device, board_width, ...: what TrainPipeline and the trainer read) is lane 0's: the lanes hold the same weights
+        if name == "lanes":
+            raise AttributeError(name)
+        return getattr(self.lanes[0], name)
+
     def set_params(self, model_params, **kw):
         for ln in self.lanes:
             ln.set_params(model_params, **kw)
+
+    def load_device_params(self, tensors, stream=None):
+        """The trainer's refresh (device tensors -> every lane's packed weights, no host round trip)."""
+        for ln in self.lanes:
+            ln.load_device_params(tensors, stream)
+
+    def trunk_overflows(self):
+        return sum(ln.trunk_overflows() for ln in self.lanes)
 
     def params(self):
         return self.lanes[0].params()

@@ -317,18 +317,29 @@ class HipTrainer(object):
             self._eval = None
 
 
-def policy_update(trainer, mini_batch, learn_rate=1e-3, lr_multiplier=1.0, epochs=8, kl_targ=0.02, evaluator=None):
+def explained_variance(winner_z, value):
+    """train_mxnet.py:222-227: 1 - Var(z - v) / Var(z) (NumPy semantics: a constant z gives nan / -inf, as there)."""
+    z = np.asarray(winner_z, dtype=np.float64)
+    v = np.asarray(value, dtype=np.float64).reshape(-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(1.0 - np.var(z - v) / np.var(z))
+
+
+def policy_update(trainer, mini_batch, learn_rate=1e-3, lr_multiplier=1.0, epochs=8, kl_targ=0.02, evaluator=None, monitors=None):
     """train_mxnet.py:194-240: epochs x train_step with KL early stop and the adaptive LR multiplier.
     mini_batch: list of (state, mcts_prob, winner_z).  `evaluator.policy_value(states)` (the HIP
     PolicyValueNet) supplies old/new predictions when given, else the trainer's own inference
-    graph.  -> (loss, entropy, kl, lr_multiplier)"""
+    graph.  -> (loss, entropy, kl, lr_multiplier); `monitors` (a dict, optional) receives the reference's value-head
+    monitors explained_var_old / explained_var_new (train_mxnet.py:222-227) and the learning rate used."""
     states = np.stack([np.ascontiguousarray(d[0]) for d in mini_batch]).astype(np.float32)
     pis = np.stack([d[1] for d in mini_batch]).astype(np.float32)
     zs = np.array([d[2] for d in mini_batch], dtype=np.float32)
     pv = (evaluator.policy_value if evaluator is not None else trainer.policy_value)
     old_probs, old_v = pv(states)
+    new_v = old_v
     loss = entropy = kl = 0.0
     batch = trainer.upload(states, pis, zs) if hasattr(trainer, "upload") else states     # once for all epochs
+    lr_used = lr_multiplier                               # (the reference logs learn_rate * the multiplier the epochs ran with)
     for _ in range(epochs):
         loss, entropy = trainer.train_step(batch, pis, zs, learn_rate * lr_multiplier)
         if evaluator is not None:
@@ -344,4 +355,8 @@ def policy_update(trainer, mini_batch, learn_rate=1e-3, lr_multiplier=1.0, epoch
         lr_multiplier /= 1.5
     elif kl < kl_targ / 2 and lr_multiplier < 20:
         lr_multiplier *= 1.5
+    if monitors is not None:
+        monitors["explained_var_old"] = explained_variance(zs, old_v)
+        monitors["explained_var_new"] = explained_variance(zs, new_v)
+        monitors["learn_rate"] = float(learn_rate * lr_used)
     return loss, entropy, kl, lr_multiplier

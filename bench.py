@@ -166,10 +166,19 @@ def exchange_probe_world1(rows, timeout_s=75.0):
             os.killpg(p.pid, 9)
         except OSError:
             pass
+        out = b""
         try:
-            p.communicate(timeout=5)
+            out, _ = p.communicate(timeout=5)
         except Exception:      # noqa: BLE001
             pass
+        for ln in reversed((out or b"").decode(errors="replace").strip().splitlines()):      # the line may have been printed
+            if ln.startswith("{"):                                                            # before the child got stuck
+                try:
+                    obj = json.loads(ln)
+                    obj["process"] = "child process, process group of one rank (killed at the deadline after it had answered)"
+                    return obj
+                except ValueError:
+                    pass
         return {"error": "the one-rank process group did not answer within %.0f s (child killed or abandoned)" % timeout_s}
     except Exception as e:            # noqa: BLE001 -- reported on the line
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
@@ -646,8 +655,11 @@ def main():
         return
     if args.exchange_probe > 0:
         dist.init(force=True)                        # a process group of THIS rank alone: RCCL when there is a GPU, else gloo
-        print(json.dumps(dist.measure_exchange(args.exchange_probe)))
-        return
+        print(json.dumps(dist.measure_exchange(args.exchange_probe)), flush=True)
+        try:
+            dist.shutdown()
+        finally:
+            os._exit(0)                              # a backend that hangs in its teardown must not cost the printed line
     if args.only_arith:
         mean_plies, _ = load_mean_plies()
         obj = arith_line(args.only_arith, 0, max(1, min(int(os.environ.get("APZ_HOST_THREADS", "16")), host_cpu_share())), args.games,

@@ -50,6 +50,10 @@ def test_async_schedule_runs_the_sgf_bootstrap_batches_first(golden_dir, tmp_pat
     # ... and count as game batches: only game_batch_num - sgf_batches = 2 self-play games are waited for
     assert hist[-1]["games_collected"] >= 2 and pipe.updates_done >= 3
     assert [r["batch"] for r in th if not r.get("sgf")][-1] == 4 + hist[-1]["games_collected"]
+    # self-play starts from the bootstrapped net (train_mxnet.py:268-272): round 1 plays nothing and installs the weights of the
+    # last bootstrap update; no game was played, let alone counted, before that
+    assert hist[0]["games"] == 0 and hist[0]["leaf_evals"] == 0 and hist[0]["version"] == len([r for r in sgf_recs if "loss" in r])
+    assert hist[0]["games_collected"] == 0 and pipe.updates_skipped == 0
     assert pipe.weights_version == pipe.updates_done                     # the self-play evaluator ended on the last snapshot
     np.testing.assert_array_equal(net.params()["w"], trainer.get_params()["w"])
     pipe.engine.close()

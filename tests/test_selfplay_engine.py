@@ -187,7 +187,7 @@ def test_laned_evaluator_routes_slots_to_lanes():
 
     a, b = Lane("a"), Lane("b")
     ev = LanedEvaluator([a, b])
-    assert (ev.n_slots, ev.batchsize, ev.hw, ev.code_stride) == (3, 32, 64, 80)
+    assert (ev.n_slots, ev.batchsize, ev.hw, ev.code_stride) == (6, 32, 64, 80)     # two lanes x three slots each
     codes = np.zeros((5, 80), np.uint8)
     assert ev.submit_codes_slot(0, codes) == 5 and ev.wait_slot(0, 5) == "a"
     assert ev.submit_codes_slot(1, codes) == 5 and ev.wait_slot(1, 5) == "b"

@@ -79,12 +79,21 @@ def test_policy_update_reduces_loss_and_adapts_lr():
     batch = [(states[i], pis[i], zs[i]) for i in range(32)]
     first = None
     mult = 1.0
+    mons = []
     for it in range(6):
-        loss, ent, kl, mult = policy_update(tr, batch, learn_rate=5e-3, lr_multiplier=mult, epochs=3, kl_targ=0.02)
+        mon = {}
+        old_v = tr.policy_value(states)[1]
+        loss, ent, kl, mult = policy_update(tr, batch, learn_rate=5e-3, lr_multiplier=mult, epochs=3, kl_targ=0.02, monitors=mon)
         first = loss if first is None else first
         assert np.isfinite(loss) and np.isfinite(ent) and kl >= -1e-6
+        # the value head's monitors (train_mxnet.py:222-227), restated here in the reference's own words
+        want_old = 1 - np.var(np.array(zs) - old_v.flatten()) / np.var(np.array(zs))
+        want_new = 1 - np.var(np.array(zs) - tr.policy_value(states)[1].flatten()) / np.var(np.array(zs))
+        assert abs(mon["explained_var_old"] - want_old) < 1e-6 and abs(mon["explained_var_new"] - want_new) < 1e-6
+        mons.append(mon)
     assert loss < first
     assert 0.05 / 1.5 <= mult <= 20 * 1.5
+    assert mons[-1]["explained_var_new"] > mons[0]["explained_var_old"]      # the value head learns the 32 outcomes
 
 
 def test_product_trainer_has_no_cpu_path():
