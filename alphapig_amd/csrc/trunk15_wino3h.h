@@ -260,21 +260,36 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
         // the patch rows come out of LDS one MFMA slot before the row pass uses them (slice 0 only issues the reads: an
         // in-order wave that waits for an LDS round trip right behind its reads cannot issue its next MFMAs meanwhile)
         float xhl[5], xhr[5];                          // the halo columns (-1 and 4) of the five patch rows
+#ifndef APZH_HALO_DPP
+#define APZH_HALO_DPP 0      /* 1: the halo columns (-1 and 4) from the neighbouring tile lanes by DPP instead of two 4-way conflicted LDS reads per row */
+#endif
+        const unsigned col0_mask = ttx == 0 ? 0u : 0xffffffffu;    // (APZH_HALO_DPP) column -1 of the first tile column is the zero border
         auto row_load = [&](const float* rp) {
 #pragma unroll
             for (int i = 0; i < 5; i++) {
                 const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
                 xr[i][0] = f32x2{c03[0], c03[1]};
                 xr[i][1] = f32x2{c03[2], c03[3]};
-                xhl[i] = rp[i * T::RROW - 1];
-                xhr[i] = rp[i * T::RROW + 4];
+                if (!APZH_HALO_DPP) {
+                    xhl[i] = rp[i * T::RROW - 1];
+                    xhr[i] = rp[i * T::RROW + 4];
+                }
             }
         };
         auto row_pass = [&]() {
             f32x2 xh[5];
 #pragma unroll
-            for (int i = 0; i < 5; i++)
-                xh[i] = f32x2{xhl[i], __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xhr[i]) & col16_mask)};   // (no branch)
+            for (int i = 0; i < 5; i++) {
+                if (APZH_HALO_DPP) {
+                    // the four tile columns of a tile row are the four lanes of a quad: column -1 = column 3 of the lane below,
+                    // column 4 = column 0 of the lane above (quad_perm [0,0,1,2] / [1,2,3,3]); the border lanes are masked
+                    const int l = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xr[i][1][1]), 0x90, 0xF, 0xF, true);
+                    const int r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xr[i][0][0]), 0xF9, 0xF, 0xF, true);
+                    xh[i] = f32x2{__builtin_bit_cast(float, (unsigned)l & col0_mask), __builtin_bit_cast(float, (unsigned)r & col16_mask)};
+                } else {
+                    xh[i] = f32x2{xhl[i], __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xhr[i]) & col16_mask)};   // (no branch)
+                }
+            }
 #pragma unroll
             for (int kc = 0; kc < 3; kc++) {
                 f32x2 x[5];
