@@ -246,7 +246,17 @@ __global__ __launch_bounds__(512) void trunk15_wino3_kernel(const float* __restr
             xr[i][2] = f32x2{3.f, 4.f};
 #else
             const f32x4 c03 = *reinterpret_cast<const f32x4*>(rp + i * T::RROW);
+#ifdef APZ3_HALO_DPP                  /* experiment (round 6): the halo columns from the neighbouring tile lanes (a quad = the four tile columns of a tile row) instead of two 4-way conflicted LDS reads */
+            {
+                const float c3 = c03[3], c0 = c03[0];
+                const int l = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, c3), 0x90, 0xF, 0xF, true);     // quad_perm [0,0,1,2]
+                const int r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, c0), 0xF9, 0xF, 0xF, true);     // quad_perm [1,2,3,3]
+                xr[i][0] = f32x2{__builtin_bit_cast(float, (unsigned)l & (ttx == 0 ? 0u : 0xffffffffu)),
+                                 __builtin_bit_cast(float, (unsigned)r & (ttx == 3 ? 0u : 0xffffffffu))};
+            }
+#else
             xr[i][0] = f32x2{rp[i * T::RROW - 1], rp[i * T::RROW + 4]};
+#endif
             xr[i][1] = f32x2{c03[0], c03[1]};
             xr[i][2] = f32x2{c03[2], c03[3]};
 #endif

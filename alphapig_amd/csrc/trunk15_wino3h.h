@@ -261,7 +261,8 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
         // in-order wave that waits for an LDS round trip right behind its reads cannot issue its next MFMAs meanwhile)
         float xhl[5], xhr[5];                          // the halo columns (-1 and 4) of the five patch rows
 #ifndef APZH_HALO_DPP
-#define APZH_HALO_DPP 0      /* 1: the halo columns (-1 and 4) from the neighbouring tile lanes by DPP instead of two 4-way conflicted LDS reads per row */
+#define APZH_HALO_DPP 1      /* the halo columns (-1 and 4) from the neighbouring tile lanes by DPP; 0: two LDS reads per row, 4-way bank
+                                conflicted (36 % of the kernel's LDS cycles): 65.1 / 68.7 us instead of 62.0 / 65.6 (profiles/r06_wino3h.md) */
 #endif
         const unsigned col0_mask = ttx == 0 ? 0u : 0xffffffffu;    // (APZH_HALO_DPP) column -1 of the first tile column is the zero border
         auto row_load = [&](const float* rp) {
@@ -283,8 +284,10 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 if (APZH_HALO_DPP) {
                     // the four tile columns of a tile row are the four lanes of a quad: column -1 = column 3 of the lane below,
                     // column 4 = column 0 of the lane above (quad_perm [0,0,1,2] / [1,2,3,3]); the border lanes are masked
-                    const int l = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xr[i][1][1]), 0x90, 0xF, 0xF, true);
-                    const int r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xr[i][0][0]), 0xF9, 0xF, 0xF, true);
+                    // (scalar copies first: hipcc 7.2 takes element 0 when __builtin_bit_cast is applied to a vector element directly)
+                    const float c3 = xr[i][1][1], c0 = xr[i][0][0];
+                    const int l = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, c3), 0x90, 0xF, 0xF, true);
+                    const int r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, c0), 0xF9, 0xF, 0xF, true);
                     xh[i] = f32x2{__builtin_bit_cast(float, (unsigned)l & col0_mask), __builtin_bit_cast(float, (unsigned)r & col16_mask)};
                 } else {
                     xh[i] = f32x2{xhl[i], __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xhr[i]) & col16_mask)};   // (no branch)
