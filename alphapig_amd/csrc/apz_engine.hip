@@ -21,6 +21,7 @@
 #include "trunk15_wino3s.h"
 #include "trunk15_wino3b.h"
 #include "trunk15_wino3h.h"
+#include "conv8_split.h"
 #include "conv8_small.h"
 #include "wgrad_wino3.h"
 #include "sampler.h"
@@ -67,6 +68,8 @@ struct ConvLayer {
     void* upk3b = nullptr;  // trunk15_wino3b_kernel (apz_set_trunk_arith(APZ_ARITH_BF16X3) only): U as three bf16 terms (Wino3B)
     void* upk3h = nullptr;  // trunk15_wino3h_kernel (APZ_ARITH_F16X2 only): U S[co] as two fp16 terms (Wino3H)
     float* bias3h = nullptr;   // ... and its [128 biases][128 x 1 / S[co]]
+    void* wpk8h = nullptr;  // conv8h_kernel (8x8 boards, APZ_ARITH_F16X2, C_in a multiple of 64): w S[co] as two fp16 terms (Conv8H)
+    float* bias8h = nullptr;   // ... and its [cout biases][cout x 1 / S[co]]
     float* bias = nullptr;
 };
 
@@ -125,7 +128,7 @@ struct apz_engine {
     bool small8 = false;    // 8x8 boards: conv8_kernel / head8_kernel (conv8_small.h)
     float* wfc_raw = nullptr;   // head8_kernel: the policy FullyConnected weight as stored, [hw][4 hw]
     int act_ps = 0, act_rs = 0;
-    bool lds_attr_set[32] = {false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done, per kernel variant
+    bool lds_attr_set[40] = {false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done, per kernel variant
     int conv_lds_set[16] = {0};
     // persistent sampler staging (apz_sample_moves_host)
     int32_t* smp_vis = nullptr;
@@ -480,8 +483,8 @@ int launch_wino3h_t(apz_engine* e, int attr_slot, const ConvLayer& L, const floa
 int launch_trunk_wino3(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
     if (e->trunk_arith == APZ_ARITH_F16X2 && !e->force_f32 && L.upk3h && e->ovf_cur &&
         (n > apz::Wino3S::MAX_BOARDS || e->no_small_trunk)) {
-        if (resid) return launch_wino3h_t<true>(e, 28, L, in, resid, out, n);
-        return launch_wino3h_t<false>(e, 29, L, in, resid, out, n);
+        if (resid) return launch_wino3h_t<true>(e, 32, L, in, resid, out, n);
+        return launch_wino3h_t<false>(e, 33, L, in, resid, out, n);
     }
     if (e->trunk_arith == APZ_ARITH_BF16X3 && L.upk3b && (n > apz::Wino3S::MAX_BOARDS || e->no_small_trunk)) {
         if (resid) return launch_wino3b_t<true>(e, 26, L, in, resid, out, n);
@@ -543,9 +546,30 @@ int launch_conv8_t(apz_engine* e, const ConvLayer& L, const float* in, const flo
     return APZ_OK;
 }
 
+// ... with split operands on the fp16 matrix pipe (conv8_split.h): same items, same grids
+template <bool RESID>
+int launch_conv8h_t(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n) {
+    using T = apz::Conv8H;
+    bool& configured = e->lds_attr_set[34 + (RESID ? 1 : 0)];
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void*)apz::conv8h_kernel<RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        configured = true;
+    }
+    const long items = (long)n * (L.cout / 16);
+    const int grid = (int)std::min<long>(items, 2L * e->num_cu);
+    hipLaunchKernelGGL((apz::conv8h_kernel<RESID>), dim3(grid), dim3(256), T::LDS_BYTES, e->stream, in, (const void*)L.wpk8h,
+                       L.bias8h, resid, out, n, L.cin, L.cout, 1, e->ovf_cur);
+    HIP_TRY(hipGetLastError());
+    return APZ_OK;
+}
+
 int launch_conv8(apz_engine* e, const ConvLayer& L, const float* in, const float* resid, float* out, int n,
                  const unsigned char* codes = nullptr) {
     if (L.cout % 16 || !L.wpk12) return fail(APZ_E_UNSUPPORTED, "conv8: C_out must be a multiple of 16");
+    if (!codes && e->trunk_arith == APZ_ARITH_F16X2 && !e->force_f32 && L.wpk8h && e->ovf_cur) {
+        if (resid) return launch_conv8h_t<true>(e, L, in, resid, out, n);
+        return launch_conv8h_t<false>(e, L, in, nullptr, out, n);
+    }
     if (codes) return launch_conv8_t<false, true>(e, L, (const float*)codes, nullptr, out, n);
     if (resid) return launch_conv8_t<true, false>(e, L, in, resid, out, n);
     return launch_conv8_t<false, false>(e, L, in, nullptr, out, n);
@@ -765,6 +789,8 @@ void apz_destroy(apz_engine* e) {
         if (l.upk3b) hipFree(l.upk3b);
         if (l.upk3h) hipFree(l.upk3h);
         if (l.bias3h) hipFree(l.bias3h);
+        if (l.wpk8h) hipFree(l.wpk8h);
+        if (l.bias8h) hipFree(l.bias8h);
         if (l.wpk12) hipFree(l.wpk12);
         if (l.bias) hipFree(l.bias);
     }
@@ -937,6 +963,16 @@ int apz_load_weights(apz_engine* e, const char* const* names, const float* const
                     }
             rc = upload(&L.wpk12, pk12);
             if (rc) return rc;
+            if (e->trunk_arith == APZ_ARITH_F16X2 && apz::Conv8H::supports(L.cin, L.cout)) {
+                // the same folded weights, per output channel times a power of two, as two fp16 terms: conv8_split.h
+                std::vector<uint16_t> pkh;
+                std::vector<float> b8;
+                apz::conv8h_pack_host(w, scale.data(), shift.data(), L.cin, L.cout, pkh, b8);
+                if (!L.wpk8h) HIP_TRY(hipMalloc(&L.wpk8h, apz::Conv8H::pk_bytes(L.cin, L.cout)));
+                HIP_TRY(hipMemcpy(L.wpk8h, pkh.data(), apz::Conv8H::pk_bytes(L.cin, L.cout), hipMemcpyHostToDevice));
+                rc = upload(&L.bias8h, b8);
+                if (rc) return rc;
+            }
         }
         if (x4) {
             // F(4x4,3x3) Winograd weights U[pos = 6i+k][co][ci] = (G g G^T)[i][k] of the BN-folded kernel g, in double,
@@ -1414,6 +1450,12 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
             if (e->small8 && L.wpk12)
                 hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale,
                                    L.wpk12, L.cin, n4, ncot, 1);
+            if (e->small8 && e->trunk_arith == APZ_ARITH_F16X2 && apz::Conv8H::supports(L.cin, L.cout) && L.cin <= 256) {
+                if (!L.wpk8h) HIP_TRY(hipMalloc(&L.wpk8h, apz::Conv8H::pk_bytes(L.cin, L.cout)));
+                if (!L.bias8h) HIP_TRY(hipMalloc(&L.bias8h, 2 * (size_t)L.cout * sizeof(float)));
+                hipLaunchKernelGGL(apz::pack_conv8h_kernel, dim3(L.cout), dim3(256), 0, st, w, scale, shift, (unsigned short*)L.wpk8h,
+                                   L.bias8h, L.cin, L.cout);
+            }
             HIP_TRY(hipGetLastError());
         }
         const int C = e->clast, hw = e->hw;
@@ -2172,8 +2214,10 @@ int apz_set_trunk_arith(apz_engine* e, int arith) {
     if (!e || (arith != APZ_ARITH_F32 && arith != APZ_ARITH_BF16X3 && arith != APZ_ARITH_F16X2))
         return fail(APZ_E_ARG, "bad trunk arithmetic");
     EngineLock guard(e->submit_lock);
-    if (arith != APZ_ARITH_F32 && !e->ring)
-        return fail(APZ_E_UNSUPPORTED, "the split trunk kernels exist for the 15x15 / 128-filter residual net only");
+    if (arith == APZ_ARITH_BF16X3 && !e->ring)
+        return fail(APZ_E_UNSUPPORTED, "the bf16 x 3 trunk kernel exists for the 15x15 / 128-filter residual net only");
+    if (arith == APZ_ARITH_F16X2 && !e->ring && !e->small8)
+        return fail(APZ_E_UNSUPPORTED, "the fp16 x 2 split kernels exist for the 15x15 / 128-filter residual net and for 8x8 boards");
     if (arith == APZ_ARITH_F16X2 && !e->ovf_host) {
         HIP_TRY(hipSetDevice(e->cfg.device));
         HIP_TRY(hipHostMalloc((void**)&e->ovf_host, (APZ_MAX_SLOTS + 1) * sizeof(unsigned), hipHostMallocMapped));

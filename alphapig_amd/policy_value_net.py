@@ -36,7 +36,9 @@ class PolicyValueNet(object):
                    numerics.py), different low-order bits, 1.5x faster; an activation beyond the fp16 range makes the
                    engine repeat that forward on the exact kernel (never a silently wrong result);
           "bf16x3" three bf16 terms, six products (csrc/trunk15_wino3b.h): round 4's form, kept for comparison;
-          "auto"   (default) "f16x2" where that kernel exists (15x15, 128 filters, residual net), else "f32"."""
+          "auto"   (default) "f16x2" where such kernels exist (15x15 / 128-filter residual net; 8x8 boards), else "f32".
+        8x8 boards (round 6): "f16x2" runs every convolution with a multiple of 64 input channels on the fp16 matrix pipe with
+        split operands (csrc/conv8_split.h), for EVERY batch size: a board's bits do not depend on the batch there."""
         self.L = _native.hip()
         self.board_width, self.board_height = int(board_width), int(board_height)
         self.batchsize = int(batch_size)
@@ -55,9 +57,10 @@ class PolicyValueNet(object):
             raise EvaluatorError("apz_create failed: %s" % self.L.apz_last_error().decode())
         if trunk_arith not in ("auto", "f32", "bf16x3", "f16x2"):
             raise ValueError("trunk_arith must be 'auto', 'f32', 'f16x2' or 'bf16x3'")
+        ring15 = net_kind == "resnet" and self.board_width == 15 and self.board_height == 15 and self._n_filter == 128
+        small8 = self.board_width == 8 and self.board_height == 8
         if trunk_arith == "auto":
-            split_ok = (net_kind == "resnet" and self.board_width == 15 and self.board_height == 15 and self._n_filter == 128)
-            trunk_arith = "f16x2" if split_ok else "f32"
+            trunk_arith = "f16x2" if (ring15 or small8) else "f32"
         self.trunk_arith = trunk_arith
         if trunk_arith != "f32":                                     # before the weights are loaded: they are packed for it
             self._ck(self.L.apz_set_trunk_arith(self._h, {"bf16x3": 1, "f16x2": 2}[trunk_arith]))

@@ -299,7 +299,11 @@ int apz_set_profiling(apz_engine *e, int on);
  * An activation beyond the fp16 range (|x| > ~655) shows as a non-finite output; the kernel raises a word and the entry
  * point that collects the forward (apz_wait, apz_forward_host, apz_forward_codes_host, apz_forward, apz_forward_codes_async
  * -- the last two then return with the stream drained) repeats it on the exact-fp32 kernel: results are always finite-
- * checked, never silently wrong.  apz_trunk_overflows: how many forwards were repeated. */
+ * checked, never silently wrong.  apz_trunk_overflows: how many forwards were repeated.
+ * 8x8 boards (policy_value_net_mxnet_simple.py:68-92 and the 8x8 residual nets): APZ_ARITH_F16X2 runs every 3x3 convolution
+ * with a multiple of 64 input channels on csrc/conv8_split.h (the same two-term split, no Winograd transform: activations up
+ * to 65 504 are in range) for EVERY batch size, the first layer on conv8_kernel; same overflow word, same repeat.
+ * APZ_ARITH_BF16X3 exists for the 15x15 / 128-filter net only (APZ_E_UNSUPPORTED elsewhere). */
 #define APZ_ARITH_F32 0
 #define APZ_ARITH_BF16X3 1
 #define APZ_ARITH_F16X2 2

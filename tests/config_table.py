@@ -58,13 +58,13 @@ def config1(n_games=4):
     return out
 
 
-def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None, lanes=1, pipeline=2):
+def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None, lanes=1, pipeline=2, trunk_arith="auto"):
     """lanes > 1: one evaluator handle (own HIP stream, own buffers) per pipeline group -- policy_value_net.LanedEvaluator."""
     from alphapig_amd.policy_value_net import LanedEvaluator, PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
     prm = weights.init_params(kind, w, w, 9, n_blocks, 128, seed=0, style="bench")
     net = PolicyValueNet(w, w, batch_size=max(16, G // pipeline), n_blocks=n_blocks, n_filter=128, model_params=prm,
-                         net_kind=kind)
+                         net_kind=kind, trunk_arith=trunk_arith)
     if lanes > 1:
         net = LanedEvaluator.like(net, lanes)
     eng = SelfPlayEngine(net, w, w, nrow, n_games=G, n_playout=npl, temp=1.0, base_seed=77, pipeline=pipeline,
@@ -81,7 +81,8 @@ def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None, la
            "moves_per_s": (eng.stats["moves"] - m0) / dt, "games_finished": eng.stats["games"] - g0,
            "ms_per_step": 1e3 * dt / steps, "host_tree_s": eng.timers["host_s"], "evaluator_s": eng.timers["eval_s"],
            "tree_arena_gb": info0["arena_bytes"] / 1e9, "tree_arena_pretouched": info0["pretouched"],
-           "peak_tree_nodes": eng.pool.pool_info()["peak_nodes"], "evaluator_lanes": lanes, "pipeline_groups": pipeline}
+           "peak_tree_nodes": eng.pool.pool_info()["peak_nodes"], "evaluator_lanes": lanes, "pipeline_groups": pipeline,
+           "trunk_arith": net.trunk_arith, "trunk_overflows": net.trunk_overflows()}
     if eng.stats["games"] - g0 > 0:
         res["mean_plies_finished"] = (eng.stats["plies"] - p0) / (eng.stats["games"] - g0)
         res["games_per_s_finished"] = (eng.stats["games"] - g0) / dt
@@ -90,13 +91,13 @@ def gpu_config(kind, w, nrow, npl, G, steps, n_blocks=10, temp_schedule=None, la
     return res
 
 
-def config2_roofline(n=32):
+def config2_roofline(n=32, trunk_arith="auto"):
     """The six convolutions of the simple net at the batch BASELINE config 2 launches (32 boards = half of the 64
     concurrent games): conv8_kernel's time per launch (HIP events over 200 back-to-back launches, apz_conv3x3_bench)
     against the fp32 matrix pipe.  The dominant kernel of the configuration is the 256 -> 256 layer."""
     from alphapig_amd.policy_value_net import PolicyValueNet
     prm = weights.init_params("simple", 8, 8, 9, 10, 128, seed=0, style="bench")
-    net = PolicyValueNet(8, 8, batch_size=n, model_params=prm, net_kind="simple")
+    net = PolicyValueNet(8, 8, batch_size=n, model_params=prm, net_kind="simple", trunk_arith=trunk_arith)
     planes = (np.random.RandomState(3).rand(n, 9, 8, 8) < 0.2).astype(np.float32)
     net.forward_planes(planes)
     chans = [9, 64, 64, 128, 128, 256, 256]
