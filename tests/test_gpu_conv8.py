@@ -180,7 +180,7 @@ def test_f16x2_overflow_repeats_the_forward_on_the_exact_kernel_8x8():
     # ordinary weights afterwards: no repeat, the split kernel's own results
     split.set_params(prm)
     q = split.forward_with_logits(planes)
-    assert split.trunk_overflows() == 8
+    assert split.trunk_overflows() == 7
     np.testing.assert_allclose(q[0], net_ref.forward(prm, planes, "simple", dtype=np.float64)[0], rtol=0, atol=LOGIT_ATOL)
     exact.close()
     split.close()
