@@ -261,10 +261,11 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
         // in-order wave that waits for an LDS round trip right behind its reads cannot issue its next MFMAs meanwhile)
         float xhl[5], xhr[5];                          // the halo columns (-1 and 4) of the five patch rows
 #ifndef APZH_HALO_DPP
-#define APZH_HALO_DPP 1      /* the halo columns (-1 and 4) from the neighbouring tile lanes by DPP; 0: two LDS reads per row, 4-way bank
+#define APZH_HALO_DPP 2      /* the halo columns (-1 and 4) from the neighbouring tile lanes by DPP; 0: two LDS reads per row, 4-way bank
                                 conflicted (36 % of the kernel's LDS cycles): 65.1 / 68.7 us instead of 62.0 / 65.6 (profiles/r06_wino3h.md) */
 #endif
         const unsigned col0_mask = ttx == 0 ? 0u : 0xffffffffu;    // (APZH_HALO_DPP) column -1 of the first tile column is the zero border
+        const float c4l = ttx == 0 ? 0.f : 4.f;                    // (APZH_HALO_DPP == 2) ... as the coefficient its only use carries
         auto row_load = [&](const float* rp) {
 #pragma unroll
             for (int i = 0; i < 5; i++) {
@@ -281,7 +282,9 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
             f32x2 xh[5];
 #pragma unroll
             for (int i = 0; i < 5; i++) {
-                if (APZH_HALO_DPP) {
+                if (APZH_HALO_DPP == 2) {
+                    xh[i] = f32x2{0.f, 0.f};              // (unused: the halo columns are taken from the row-pass RESULTS below)
+                } else if (APZH_HALO_DPP) {
                     // the four tile columns of a tile row are the four lanes of a quad: column -1 = column 3 of the lane below,
                     // column 4 = column 0 of the lane above (quad_perm [0,0,1,2] / [1,2,3,3]); the border lanes are masked
                     // (scalar copies first: hipcc 7.2 takes element 0 when __builtin_bit_cast is applied to a vector element directly)
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 }
             }
 #pragma unroll
-            for (int kc = 0; kc < 3; kc++) {
+            for (int kc = 0; kc < (APZH_HALO_DPP == 2 ? 2 : 3); kc++) {
                 f32x2 x[5];
 #pragma unroll
                 for (int i = 0; i < 5; i++) x[i] = kc < 2 ? xr[i][kc] : xh[i];
@@ -310,12 +313,29 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                     tt[2][kc] = fma2(4.f, x[0], fma2(-5.f, x[2], x[4]));
                 }
             }
+            if (APZH_HALO_DPP == 2) {
+                // The row pass works on columns, and a tile's halo columns ARE columns of its neighbours: column -1 = column 3 of
+                // the tile to the left (its pair 1, element 1), column 4 = column 0 of the tile to the right (pair 0, element 0), and
+                // the four tile columns of a tile row are the four lanes of a quad -- so the halo pair of every row-pass result
+                // comes from the neighbouring lanes' results (quad_perm [0,0,1,2] / [1,2,3,3]; the same operations on the same
+                // words: the same bits) instead of from a row pass of its own: 6 moves instead of 10 moves, 10 selects and 5 - 6
+                // packed operations per chunk.  Border lanes: the left one is zeroed by its coefficient in col_pass (c4l), the
+                // right one by a mask here.  (scalar copies first: hipcc 7.2 takes element 0 when __builtin_bit_cast is applied to
+                // a vector element directly)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float c3 = tt[j][1][1], c0 = tt[j][0][0];
+                    const int l = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, c3), 0x90, 0xF, 0xF, true);
+                    const int r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, c0), 0xF9, 0xF, 0xF, true);
+                    tt[j][2] = f32x2{__builtin_bit_cast(float, l), __builtin_bit_cast(float, (unsigned)r & col16_mask)};
+                }
+            }
         };
         // B^T over the columns of one row: v = (v1, v2), (v3, v4), (v0, v5) -> o[0..5]
         auto col_pass = [&](const f32x2* t, float* o) {
             const f32x2 ab = fma2(-4.f, t[0], t[1]);   // (b, a) = (v3 - 4 v1, v4 - 4 v2)
             const f32x2 dc = t[1] - t[0];              // (d, c) = (v3 - v1, v4 - v2)
-            o[0] = __builtin_fmaf(4.f, t[2][0], __builtin_fmaf(-5.f, t[0][1], t[1][1]));
+            o[0] = __builtin_fmaf(APZH_HALO_DPP == 2 ? c4l : 4.f, t[2][0], __builtin_fmaf(-5.f, t[0][1], t[1][1]));
             o[3] = __builtin_fmaf(2.f, dc[0], dc[1]);
             o[1] = ab[1] + ab[0];
             o[4] = __builtin_fmaf(-2.f, dc[0], dc[1]);
@@ -475,26 +495,58 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 asm volatile("" : "+v"(le));
                 const int b_hi = wpos0 * T::VPOS + (le & 31) * 16;                   // B = [Vhi | Vhi]
                 const int b_lo = b_hi + T::VTERM;                                    // B = [Vlo | Vlo]
+#ifndef APZH_BDEDUP
+#define APZH_BDEDUP 0
+#endif
+#if APZH_BDEDUP
+                // ONE read per position: lanes 0-31 fetch the lo term, lanes 32-63 the hi term; the two fragments [Vlo | Vlo] and
+                // [Vhi | Vhi] are made in registers (v_permlane32_swap_b32: lanes 32-63 of the first operand <-> lanes 0-31 of the second)
+                const int b_mix = b_hi + ((le & 32) ? 0 : T::VTERM);
+                u32x4 bmix = *reinterpret_cast<const u32x4*>(vp + b_mix);
+                auto bsplit = [&]() {
+                    u32x4 lo4 = bmix, hi4 = bmix;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+                                 "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+                                 : "+v"(lo4[0]), "+v"(lo4[1]), "+v"(lo4[2]), "+v"(lo4[3]), "+v"(hi4[0]), "+v"(hi4[1]), "+v"(hi4[2]), "+v"(hi4[3]));
+                    bfr[1] = __builtin_bit_cast(f16x8, lo4);
+                    bfr[0] = __builtin_bit_cast(f16x8, hi4);
+                };
+                bsplit();
+#else
                 bfr[0] = *reinterpret_cast<const f16x8*>(vp + b_hi);
                 bfr[1] = *reinterpret_cast<const f16x8*>(vp + b_lo);
+#endif
+#if APZH_BDEDUP
+#define APZH_BREAD_LO(p9)
+#define APZH_BREAD_HI(p9) if (p9 + 1 < 9 && !APZH_ABL_B) bmix = *reinterpret_cast<const u32x4*>(vp + b_mix + pos_off(p9 + 1));
+#define APZH_BSPLIT(p9) if (p9 + 1 < 9 && !APZH_ABL_B) bsplit();
+#else
+#define APZH_BREAD_LO(p9) if (p9 + 1 < 9 && !APZH_ABL_B) bfr[1] = *reinterpret_cast<const f16x8*>(vp + b_lo + pos_off(p9 + 1));
+#define APZH_BREAD_HI(p9) if (p9 + 1 < 9 && !APZH_ABL_B) bfr[0] = *reinterpret_cast<const f16x8*>(vp + b_hi + pos_off(p9 + 1));
+#define APZH_BSPLIT(p9)
+#endif
 #define APZH_SLOT(k)                                                                                                     \
                 {                                                                                                        \
                     constexpr int p9 = (k), slot = (par * 9 + (k)) % RING;                                               \
                     /* the small products first: (Whi + Wlo) . Vlo, then (Whi + Wlo) . Vhi; every V fragment is re-read   \
                        for the next position right behind the MFMA that uses it */                                        \
                     APZH_MFMA_LO(APZH_AF(slot), bfr[1], acc[p9]);                                                        \
-                    if (p9 + 1 < 9 && !APZH_ABL_B) bfr[1] = *reinterpret_cast<const f16x8*>(vp + b_lo + pos_off(p9 + 1)); \
+                    APZH_BREAD_LO(p9)                                                                                    \
                     APZH_MFMA_HI(APZH_AF(slot), bfr[0], acc[p9]);                                                        \
-                    if (p9 + 1 < 9 && !APZH_ABL_B) bfr[0] = *reinterpret_cast<const f16x8*>(vp + b_hi + pos_off(p9 + 1)); \
+                    APZH_BREAD_HI(p9)                                                                                    \
                     if ((k) == 1 && !APZH_ABL_D) raw_dma(t, c + 2, par);                                                 \
                     APZH_TSLICE(2 * (k))                                                                                 \
                     APZH_TSLICE(2 * (k) + 1)                                                                             \
                     /* unit k + RING - 1 goes into the ring slot of unit k - 1, whose MFMAs are done */                 \
                     APZH_ULOAD(k)                                                                                        \
+                    APZH_BSPLIT(p9)                                                                                      \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                 }
                 APZH_SLOT(0) APZH_SLOT(1) APZH_SLOT(2) APZH_SLOT(3) APZH_SLOT(4) APZH_SLOT(5) APZH_SLOT(6) APZH_SLOT(7) APZH_SLOT(8)
 #undef APZH_SLOT
+#undef APZH_BREAD_LO
+#undef APZH_BREAD_HI
+#undef APZH_BSPLIT
                 APZH_AF_KEEP(0) APZH_AF_KEEP(1) APZH_AF_KEEP(2) APZH_AF_KEEP(3) APZH_AF_KEEP(4) APZH_AF_KEEP(5)
                 APZH_STAMP(2)
             };
