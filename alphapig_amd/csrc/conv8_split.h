@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256) void conv8h_kernel(const float* __restrict__ i
     const int st_cell = ((lane >> 3) + 1) * T::RSB + ((lane & 7) + 1) * T::CELL;
     // B fragment of lane (pixel j of a 16-pixel tile = two board rows, k group kg): channels 8 (kg & 1) .. + 7
     const int brd = (j >> 3) * T::RSB + (j & 7) * T::CELL + (kg & 1) * 16;
+    const int brd2 = brd + (kg >> 1) * T::TERM_BYTES;            // (APZ_CONV8H_SWAP) ... of the hi tile (kg 0, 1) or the lo tile (kg 2, 3)
+    (void)brd2;
     const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pk), 0, (unsigned)T::pk_bytes(cin, cout), 0x00020000);
     unsigned nonfinite = 0;
 
@@ -170,31 +172,57 @@ __global__ __launch_bounds__(256) void conv8h_kernel(const float* __restrict__ i
             *reinterpret_cast<u32x4*>(tile + T::TERM_BYTES + st_cell) = l[0];
             *reinterpret_cast<u32x4*>(tile + T::TERM_BYTES + st_cell + 16) = l[1];
         };
-        f16x8 wA[9], wB[9];
-        auto wload = [&](f16x8 (&dst)[9], int s) {  // the nine taps of sub-chunk s: one coalesced 1 KB load each
+#ifndef APZ_CONV8H_SWAP
+#define APZ_CONV8H_SWAP 0     /* 1: one B fragment [Xhi | Xlo] per (tap, tile) against A = [Whi | Wlo] and A' = [Wlo | Whi] (the same 1 KB
+                                 unit read with the lane halves exchanged: an L1 hit) instead of two fragments [X | X] against A: half the
+                                 LDS reads for twice the weight loads.  Measured, not faster: 256 -> 256 at 32 boards 11.9 against 11.8 us,
+                                 the smaller layers 3 - 8 % slower (profiles/r06_config2.md) */
+#endif
+#if APZ_CONV8H_SWAP
+        typedef f16x8 WFrag[18];                    // [tap][A, A']
+#else
+        typedef f16x8 WFrag[9];
+#endif
+        WFrag wA, wB;
+        auto wload = [&](WFrag& dst, int s) {       // the nine taps of sub-chunk s: one coalesced 1 KB load each
             const unsigned so = (unsigned)((cot * nsub_all + s_lo + s) * 9) * T::UNIT;
 #pragma unroll
-            for (int tap = 0; tap < 9; tap++)
+            for (int tap = 0; tap < 9; tap++) {
+#if APZ_CONV8H_SWAP
+                dst[2 * tap] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, lane * 16 + (tap & 3) * T::UNIT,
+                                                                                              so + (unsigned)(tap >> 2) * 4u * T::UNIT, 0));
+                dst[2 * tap + 1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, (lane ^ 32) * 16 + (tap & 3) * T::UNIT,
+                                                                                                  so + (unsigned)(tap >> 2) * 4u * T::UNIT, 0));
+#else
                 dst[tap] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, lane * 16 + (tap & 3) * T::UNIT,
                                                                                           so + (unsigned)(tap >> 2) * 4u * T::UNIT, 0));
+#endif
+            }
         };
-        auto compute = [&](const f16x8 (&w)[9]) {
+        auto compute = [&](const WFrag& w) {
 #pragma unroll
             for (int ky = 0; ky < 3; ky++)
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    const f16x8 a = w[ky * 3 + kx];
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
+#if APZ_CONV8H_SWAP
+                        // lanes kg 0, 1: the hi terms of channels 0-7, 8-15; kg 2, 3: the lo terms (Whi.Xhi + Wlo.Xlo, then Wlo.Xhi + Whi.Xlo)
+                        const f16x8 b = *reinterpret_cast<const f16x8*>(tile + brd2 + (2 * t + ky) * T::RSB + kx * T::CELL);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * (ky * 3 + kx) + 1], b, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * (ky * 3 + kx)], b, acc[t], 0, 0, 0);
+#else
+                        const f16x8 a = w[ky * 3 + kx];
                         const char* bp = tile + brd + (2 * t + ky) * T::RSB + kx * T::CELL;
                         const f16x8 blo = *reinterpret_cast<const f16x8*>(bp + T::TERM_BYTES);
                         const f16x8 bhi = *reinterpret_cast<const f16x8*>(bp);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, blo, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bhi, acc[t], 0, 0, 0);
+#endif
                     }
                 }
         };
-        auto turn = [&](const f16x8 (&w)[9], f16x8 (&wnext)[9], int s) {     // sub-chunk s from `w`; s + 1 prepared
+        auto turn = [&](const WFrag& w, WFrag& wnext, int s) {     // sub-chunk s from `w`; s + 1 prepared
             if (s + 1 < nsub) {
                 fetch(s + 1);
                 wload(wnext, s + 1);

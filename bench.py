@@ -360,13 +360,16 @@ def train_step_line(device, steps=10, warmup=3):
     return out
 
 
-def config2_line(device, steps=6000, warmup=800):
+def config2_line(device, steps=6000, warmup=800, trunk_arith="auto"):
     """BASELINE configs[1] (the metric's CPU-runnable sibling: 64 concurrent 8x8 games, 4 in a row, n_playout 200, the 6-conv
     net) through the same engine: leaf evaluations per second.  An EXTRA object (tests/config_table.py is the same measurement)."""
     from alphapig_amd.policy_value_net import LanedEvaluator, PolicyValueNet
     from alphapig_amd.selfplay import SelfPlayEngine
     prm = weights.init_params("simple", 8, 8, 9, N_BLOCKS, N_FILTER, seed=0, style="bench")
-    net = PolicyValueNet(8, 8, batch_size=32, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, net_kind="simple", device=device)
+    # (round 6: "auto" = "f16x2" on 8x8 boards -- the five convolutions with >= 64 input channels on conv8h_kernel, split fp16
+    # operands, fp32 accumulate: 256 -> 256 at 32 boards 23.4 -> 11.8 us; profiles/r06_config2.md)
+    net = PolicyValueNet(8, 8, batch_size=32, n_blocks=N_BLOCKS, n_filter=N_FILTER, model_params=prm, net_kind="simple", device=device,
+                         trunk_arith=trunk_arith)
     # one engine handle (own HIP stream) per pipeline group: the two groups' seven-launch forwards overlap on the GPU
     # (round 5: 337-353 k -> 402-415 k leaf evaluations per second, profiles/r05_config2.md); same games, bit for bit
     ev = LanedEvaluator.like(net, 2)
@@ -379,20 +382,32 @@ def config2_line(device, steps=6000, warmup=800):
     ev.sync()
     dt = time.perf_counter() - t
     leafs = eng.stats["leaf_evals"] - l0
+    arith, repeats = net.trunk_arith, ev.trunk_overflows()
     eng.close()
     ev.close()
     return {"workload": "64 concurrent 8x8 games, n_in_row 4, n_playout 200, simple 6-conv net, 32-board forwards, one evaluator lane "
-                        "(HIP stream) per pipeline group", "steps": steps, "evaluator_lanes": 2,
+                        "(HIP stream) per pipeline group", "steps": steps, "evaluator_lanes": 2, "trunk_arith": arith,
+            "dtype": ARITH_INFO[arith][0].replace("bf16/fp16", "fp16") if arith != "f32" else ARITH_INFO[arith][0],
+            "forwards_repeated_on_exact_kernel": repeats,
             "leaf_evals_per_s": leafs / dt, "ms_per_step": 1e3 * dt / steps}
 
 
-def config2_child(timeout_s=120.0):
+def config2_both():
+    """BASELINE configs[1] in the default arithmetic (8x8: split fp16 operands) and, beside it, on the exact-fp32 kernels: the
+    same games, the second number on the same object as `leaf_evals_per_s_exact_f32`."""
+    obj = config2_child()
+    exact = config2_child(trunk_arith="f32")
+    obj["leaf_evals_per_s_exact_f32"] = exact.get("leaf_evals_per_s") if isinstance(exact, dict) else None
+    return obj
+
+
+def config2_child(timeout_s=120.0, trunk_arith="auto"):
     """config2_line in a FRESH process: inside the bench process, after the other extras have created and destroyed half a
     dozen engines, the two lanes' streams no longer overlap (353 k instead of 385 - 415 k leaf evaluations/s, measured); a
     process that creates just these two streams gets two hardware queues.  Bounded like the exchange probe."""
     import subprocess
-    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--config2-worker"], cwd=REPO, stdout=subprocess.PIPE,
-                         stderr=subprocess.DEVNULL, start_new_session=True)
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--config2-worker", "--trunk-arith", trunk_arith], cwd=REPO,
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
     try:
         out, _ = p.communicate(timeout=timeout_s)
         obj = json.loads(out.decode().strip().splitlines()[-1])
@@ -651,7 +666,7 @@ def main():
         return
 
     if args.config2_worker:
-        print(json.dumps(config2_line(0)))
+        print(json.dumps(config2_line(0, trunk_arith=args.trunk_arith)))
         return
     if args.exchange_probe > 0:
         dist.init(force=True)                        # a process group of THIS rank alone: RCCL when there is a GPU, else gloo
@@ -1015,7 +1030,7 @@ def main():
         for key, fn in (("roofline_stem", lambda: stem_roofline(local)), ("latency", lambda: latency_probe(local)),
                         ("trunk_exact_f32" if arith != "f32" else "trunk_f16x2",
                          lambda: arith_line("f32" if arith != "f32" else "f16x2", local, threads, G, args.pipeline, mean_plies)),
-                        ("train_step", lambda: train_step_line(local)), ("config2", lambda: config2_child()),
+                        ("train_step", lambda: train_step_line(local)), ("config2", lambda: config2_both()),
                         ("cpu_baseline", lambda: cpu_baseline(mean_plies, cores=max(1, min(16, ncpu))))):
             heartbeat("extra: %s" % key)
             line[key] = fn()
