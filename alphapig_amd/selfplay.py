@@ -103,6 +103,8 @@ class SelfPlayEngine(object):
         # tests record the games they replay through the sequential oracle with it; None costs nothing)
         self.tap = None
         self._limit = None
+        self._active_epoch = 0          # bumped whenever a slot's `active` flag changes
+        self._grp_cache = {}            # group (tuple of slot ids) -> (epoch, its active slots as an int32 array)
         n_workers = min(self.pipeline, getattr(self.evaluator, "n_slots", 1)) if self._slotted else 1
         # one worker thread per slot; a worker serves its own groups in order
         self._n_slots = max(1, n_workers)
@@ -115,6 +117,8 @@ class SelfPlayEngine(object):
     def _start_game(self, s):
         slot = self.slots[s]
         if self._limit is not None and self.next_index >= self._limit:
+            if slot.active:
+                self._active_epoch += 1
             slot.active = False
             return False
         k = self.index_offset + self.next_index * self.index_stride     # global game index
@@ -123,6 +127,8 @@ class SelfPlayEngine(object):
         self.set_slot_rng(s, self.base_seed + k)
         slot.pyrnd = _random.Random(self.base_seed + k)
         slot.codes, slot.pis, slot.movers = [], [], []
+        if not slot.active:
+            self._active_epoch += 1
         slot.active = True
         self.pool.reset(s, 0)
         forced = draw_forced_opening(slot.pyrnd) if self.forced_opening else None
@@ -246,8 +252,17 @@ class SelfPlayEngine(object):
         the group's active slots (the steady state) feed + first advance are ONE native call (apzh_feed_advance).
         -> (eval_ids, eval_codes)"""
         t0 = time.perf_counter()
-        ids = np.array([s for s in ids if self.slots[s].active], dtype=np.int32)
-        fused = fed is not None and len(fed[0]) == len(ids) and np.array_equal(np.asarray(fed[0], dtype=np.int32), ids)
+        # the group's active slots: the same array object as long as no slot changed its `active` flag (the steady state of a
+        # long run) -- a round of BASELINE config 2 is ~125 us, of which rebuilding and comparing these 32-entry arrays, the
+        # masks and the concatenations below were ~15 (profiles/r06_config2.md)
+        key = ids if isinstance(ids, tuple) else tuple(ids)
+        hit = self._grp_cache.get(key)
+        if hit is None or hit[0] != self._active_epoch:
+            hit = (self._active_epoch, np.array([s for s in key if self.slots[s].active], dtype=np.int32))
+            self._grp_cache[key] = hit
+        ids = hit[1]
+        fused = fed is not None and (fed[0] is ids or (len(fed[0]) == len(ids) and
+                                                       np.array_equal(np.asarray(fed[0], dtype=np.int32), ids)))
         if fed is not None and not fused:
             self.pool.feed(fed[0], fed[1], fed[2])
         eval_ids, eval_codes = [], []
@@ -257,6 +272,9 @@ class SelfPlayEngine(object):
                 fused = False
             else:
                 st, codes = self.pool.advance(ids)
+            if not eval_ids and int(st.min()) == NEED_EVAL == int(st.max()):     # every slot waits for its leaf: nothing to sort out
+                self.timers["host_s"] += time.perf_counter() - t0
+                return ids, codes
             need = st == NEED_EVAL
             if need.any():
                 eval_ids.append(ids[need])
@@ -312,7 +330,7 @@ class SelfPlayEngine(object):
         return p, v, ids
 
     def _groups(self):
-        return [list(range(g, self.G, self.pipeline)) for g in range(self.pipeline)]
+        return [tuple(range(g, self.G, self.pipeline)) for g in range(self.pipeline)]
 
     def run_steps(self, n_steps, total_games=None):
         """Run n_steps scheduler rounds; in one round every active slot gets exactly one leaf
