@@ -1450,7 +1450,7 @@ int apz_load_weights_dev(apz_engine* e, const char* const* names, const void* co
             if (e->small8 && L.wpk12)
                 hipLaunchKernelGGL(apz::pack_direct_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, w, scale,
                                    L.wpk12, L.cin, n4, ncot, 1);
-            if (e->small8 && e->trunk_arith == APZ_ARITH_F16X2 && apz::Conv8H::supports(L.cin, L.cout) && L.cin <= 256) {
+            if (e->small8 && e->trunk_arith == APZ_ARITH_F16X2 && apz::Conv8H::supports(L.cin, L.cout)) {
                 if (!L.wpk8h) HIP_TRY(hipMalloc(&L.wpk8h, apz::Conv8H::pk_bytes(L.cin, L.cout)));
                 if (!L.bias8h) HIP_TRY(hipMalloc(&L.bias8h, 2 * (size_t)L.cout * sizeof(float)));
                 hipLaunchKernelGGL(apz::pack_conv8h_kernel, dim3(L.cout), dim3(256), 0, st, w, scale, shift, (unsigned short*)L.wpk8h,

@@ -78,33 +78,32 @@ inline void conv8h_pack_host(const float* w, const double* scale, const double* 
     }
 }
 
-// The same on the device (the trainer's refresh path): one workgroup per output channel, thread = input channel (cin <= 256).
+// The same on the device (the trainer's refresh path): one workgroup of 256 threads per output channel, a thread walks the
+// input channels tid, tid + 256, ... twice (the channel's maximum first, then the two terms).
 __global__ void pack_conv8h_kernel(const float* __restrict__ w, const double* __restrict__ scale, const double* __restrict__ shift,
                                    unsigned short* __restrict__ pk, float* __restrict__ bias8h, int cin, int cout) {
-    const int co = blockIdx.x, ci = threadIdx.x;
-    double u[9], m = 0.0;
-    if (ci < cin)
+    const int co = blockIdx.x, tid = threadIdx.x;
+    const double sc = scale[co];
+    double m = 0.0;
+    for (int ci = tid; ci < cin; ci += blockDim.x)
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            u[tap] = (double)w[((size_t)co * cin + ci) * 9 + tap] * scale[co];
-            m = fmax(m, fabs(u[tap]));
-        }
+        for (int tap = 0; tap < 9; tap++) m = fmax(m, fabs((double)w[((size_t)co * cin + ci) * 9 + tap] * sc));
     __shared__ double red[256];
-    red[ci] = m;
+    red[tid] = m;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (ci < s && ci + s < (int)blockDim.x) red[ci] = fmax(red[ci], red[ci + s]);
+        if (tid < s && tid + s < (int)blockDim.x) red[tid] = fmax(red[tid], red[tid + s]);
         __syncthreads();
     }
     const float S = Wino3H::scale_for(red[0]);
-    if (ci == 0) {
+    if (tid == 0) {
         bias8h[co] = (float)shift[co];
         bias8h[cout + co] = 1.f / S;
     }
-    if (ci < cin)
+    for (int ci = tid; ci < cin; ci += blockDim.x)
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            const double x = u[tap] * (double)S;
+            const double x = (double)w[((size_t)co * cin + ci) * 9 + tap] * sc * (double)S;
             const _Float16 hi = (_Float16)(float)x;
             const _Float16 lo = (_Float16)(float)(x - (double)(float)hi);
             pk[Conv8H::pk_index(co, ci, tap, 0, cin)] = __builtin_bit_cast(unsigned short, hi);
