@@ -654,7 +654,11 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 for (int pl = 0; pl < 4; pl++) {
                     const f32x4 pv = *reinterpret_cast<const f32x4*>(sw + pl * T::SPLANE + s_lin);
                     const unsigned vo = ((pl & 1) == 0 || two) ? ep_vo : 0x80000000u;   // the missing second board of an odd batch
+#if defined(APZH_ABL_ST) && APZH_ABL_ST     /* measurement build: no output stores (how much of the epilogue is the HBM burst?) */
+                    asm volatile("" ::"v"(pv), "v"(vo));
+#else
                     bstore(r_out, vo, (unsigned)((bd0 + (pl & 1)) * T::C + row_chan(s, 2 * wave + (pl >> 1))) * plane_b, pv);
+#endif
                 }
                 APZH_STAMP(3)
             };
