@@ -363,6 +363,26 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
             *reinterpret_cast<unsigned*>(vp) = hu;
             *reinterpret_cast<unsigned*>(vp + T::VTERM) = lu;
         };
+#ifndef APZH_EMIT2
+#define APZH_EMIT2 0
+#endif
+        // two positions at once: the two v_fma_mixlo / v_fma_mixhi pairs interleaved, so that no wait state is needed between a
+        // register's low-half write and its high-half write
+        auto emit2 = [&](char* vp0, float ev0, float od0, char* vp1, float ev1, float od1) {
+            typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+            const f16x2_ h0 = {(_Float16)ev0, (_Float16)od0}, h1 = {(_Float16)ev1, (_Float16)od1};
+            const unsigned hu0 = __builtin_bit_cast(unsigned, h0), hu1 = __builtin_bit_cast(unsigned, h1);
+            unsigned lu0, lu1;
+            asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %2, -1.0, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "=&v"(lu0), "=&v"(lu1) : "v"(hu0), "v"(hu1), "v"(ev0), "v"(ev1), "v"(od0), "v"(od1));
+            *reinterpret_cast<unsigned*>(vp0) = hu0;
+            *reinterpret_cast<unsigned*>(vp0 + T::VTERM) = lu0;
+            *reinterpret_cast<unsigned*>(vp1) = hu1;
+            *reinterpret_cast<unsigned*>(vp1 + T::VTERM) = lu1;
+        };
         // The transform of one chunk (raw[rpar] -> V[vpar], this thread's channel, rows 3 ph .. 3 ph + 2) in 18 slices, two
         // per MFMA slot of a chunk body
         auto tslice = [&](int rpar, int vpar, auto KK) {
@@ -375,7 +395,12 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 constexpr int ii = (K - 3) / 5, part = (K - 3) % 5;
                 if constexpr (part == 0) col_pass(tt[ii], oo);
                 else if constexpr (part == 1) exchange(oo);
-                else {
+                else if (APZH_EMIT2) {
+                    if constexpr (part == 2)
+                        emit2(vp + ((3 * ph + ii) * 6 + 0) * T::VPOS, oo[0], oo[3], vp + ((3 * ph + ii) * 6 + 1) * T::VPOS, oo[1], oo[4]);
+                    else if constexpr (part == 3)
+                        emit(vp + ((3 * ph + ii) * 6 + 2) * T::VPOS, oo[2], oo[5]);
+                } else {
                     constexpr int k = part - 2;
                     emit(vp + ((3 * ph + ii) * 6 + k) * T::VPOS, oo[k], oo[k + 3]);
                 }
@@ -484,6 +509,16 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
 #endif
             auto chunk = [&](int c, auto PAR) {
                 constexpr int par = decltype(PAR)::value;
+#ifndef APZH_ADDR_EARLY
+#define APZH_ADDR_EARLY 0
+#endif
+                int le_early = 0;
+                if (APZH_ADDR_EARLY) {                // the fragment offset in front of the barrier instead of behind it
+                    le_early = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    asm volatile("" : "+v"(le_early));
+                    le_early = wpos0 * T::VPOS + (le_early & 31) * 16;
+                    asm volatile("" : "+v"(le_early));
+                }
                 if (!APZH_ABL_S) __syncthreads();     // V[par] and raw[1 - par] complete; V[1 - par] and raw[par] free
                 APZH_STAMP(1)
                 ub_cur = ub_nxt;                      // (chunk 0 of item 0: set in front of the loop)
@@ -493,7 +528,7 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                 // what hipcc spills, and every scratch reload is followed by vmcnt(0): a full drain of the weight ring)
                 int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 asm volatile("" : "+v"(le));
-                const int b_hi = wpos0 * T::VPOS + (le & 31) * 16;                   // B = [Vhi | Vhi]
+                const int b_hi = APZH_ADDR_EARLY ? le_early : wpos0 * T::VPOS + (le & 31) * 16;   // B = [Vhi | Vhi]
                 const int b_lo = b_hi + T::VTERM;                                    // B = [Vlo | Vlo]
 #ifndef APZH_BDEDUP
 #define APZH_BDEDUP 0
@@ -633,14 +668,23 @@ __global__ __launch_bounds__(512) void trunk15_wino3h_kernel(const float* __rest
                         y[2][ee] = __builtin_fmaf(4.f, s34, s12);
                         y[3][ee] = __builtin_fmaf(8.f, d34, d12) + hrow[5][ee];
                     }
-                    float chk = 0.f;
+#ifndef APZH_CHK4
+#define APZH_CHK4 0      /* 1: the non-finite check on the four corner outputs of a tile only (see below) instead of all sixteen: 13 vector
+                            instructions fewer per step, no measurable change (profiles/r06_wino3h_micro_ab.log: the epilogue waits on
+                            barriers and LDS round trips, not on its vector instructions) -- so the plain form stays */
+#endif
+                    // Non-finite check.  y[a][e] sums M[i][k] over i in rows(a), k in rows(e) with rows(0) = 0..4, rows(1) = rows(2) =
+                    // 1..4, rows(3) = 1..5 (the non-zero columns of A^T): the four corners y[0][0], y[0][3], y[3][0], y[3][3] together
+                    // contain every one of the 36 M[i][k], and a NaN or an infinity in a sum stays non-finite -- so the corners'
+                    // sum is non-finite whenever any accumulator of the tile is (3 additions per step instead of 16).
+                    float chk = APZH_CHK4 ? (y[0][0] + y[0][3]) + (y[3][0] + y[3][3]) : 0.f;
 #pragma unroll
                     for (int a = 0; a < 4; a++) {
                         f32x4 v;
 #pragma unroll
                         for (int ee = 0; ee < 4; ee++) v[ee] = __builtin_fmaf(y[a][ee], is, bv);
                         if (RESID) v += *reinterpret_cast<const f32x4*>(sp + a * T::SROW);   // (wave-private: written above by this wave)
-                        chk += (v[0] + v[1]) + (v[2] + v[3]);   // an overflow of the fp16 split shows as +-inf / NaN here
+                        if (!APZH_CHK4) chk += (v[0] + v[1]) + (v[2] + v[3]);   // an overflow of the fp16 split shows as +-inf / NaN here
 #pragma unroll
                         for (int ee = 0; ee < 4; ee++) v[ee] = RELU ? fmaxf(v[ee], 0.f) : v[ee];
                         if (gtx == 3) v[3] = 0.f;      // column 15 is the halo column of the rows16 layout

@@ -221,6 +221,25 @@ int main(int argc, char** argv) {
         printf("guard: activations of 3000 (|V| up to 3e5) -> flag %u %s\n", fl, fl ? "OK" : "MISSED");
         if (!fl) bad++;
         CK(hipMemcpy(in, h.data(), big.size() * 4, hipMemcpyHostToDevice));
+        // ... and ONE activation beyond the range (every other one ordinary), at every pixel position class of a tile in turn:
+        // the kernel looks at the four corner outputs of a tile only (trunk15_wino3h.h, APZH_CHK4)
+        int missed = 0, tried = 0;
+        for (int y = 0; y < 15; y += 1)
+            for (int x = 0; x < 15; x += (y % 3 == 0 ? 1 : 4)) {
+                std::vector<float> one(h.begin(), h.begin() + 2 * 128 * 240);
+                const int ch = (7 * y + 3 * x) % 128, bd = (x + y) & 1;
+                one[((size_t)bd * 128 + ch) * 240 + y * 16 + x] = 2.0e5f;
+                CK(hipMemcpy(in, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+                launch(0, (x + y) % 2, apz::wino3_grid(2, 256), 2, out[0]);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(&fl, flag, 4, hipMemcpyDeviceToHost));
+                CK(hipMemset(flag, 0, 4));
+                tried++;
+                if (!fl) missed++;
+            }
+        printf("guard: one activation of 2e5 among ordinary ones, %d positions -> %d missed %s\n", tried, missed, missed ? "MISSED" : "OK");
+        if (missed) bad++;
+        CK(hipMemcpy(in, h.data(), big.size() * 4, hipMemcpyHostToDevice));
     }
 
     // ---- timing: interleaved rounds of the three kernels on the same data
