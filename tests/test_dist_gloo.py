@@ -213,3 +213,19 @@ def test_bench_exchange_probe_child_process_protocol():
     assert ex["bytes_sent_per_rank"] == 3000 * 1144 and ex["process"].startswith("child process")
     late = bench.exchange_probe_world1(3000, timeout_s=0.01)
     assert "error" in late and "did not answer" in late["error"]
+
+
+def test_block_copy_parallel_slices_and_page_touch():
+    """dist._block_copy (the exchange's pack / unpack of a round's 80 MB: large blocks in parallel slices) and
+    dist._touch_pages (first touch of the arrays the consumer keeps, on a helper thread under the collective): byte-exact for
+    sizes around the slice boundaries, and the touch leaves shapes alone."""
+    from alphapig_amd import dist
+    rs = np.random.RandomState(3)
+    for n in (0, 1, 4095, (8 << 20) - 1, (8 << 20) + 1, (9 << 20) + 4097, 20 << 20):
+        src = rs.randint(0, 256, n).astype(np.uint8)
+        dst = np.empty(n, np.uint8)
+        dist._block_copy(dst, src)
+        assert np.array_equal(dst, src), n
+    a, b, c = np.empty((1000, 225), np.float32), np.empty((0, 240), np.uint8), np.empty(7, np.float32)
+    dist._touch_pages((a, b, c))
+    assert a.shape == (1000, 225) and b.shape == (0, 240) and c.shape == (7,)
