@@ -124,6 +124,15 @@ class TrainPipeline(object):
         self.round_seconds = float(conf.get("round_seconds", 0.5))
         self.round_steps = conf.get("round_steps")
         self.max_update_share = float(conf.get("max_update_share", 1.0))
+        # exclusive_updates (default off): rank 0's self-play loop starts no new round while its trainer thread is inside a
+        # policy_update (the in-flight forwards finish).  Measured on one MI355X with the reference's configuration
+        # (profiles/r06_train_loop_exclusive.log / _interleaved.log): an update takes 45 ms instead of 130 (its ~200 small
+        # launches per epoch no longer queue behind the self-play forwards' 60-us full-chip kernels), but self-play is held
+        # 12 % of the wall clock and ends at 277 k leaf evaluations/s against 305 k interleaved: interleaving wins on
+        # throughput; the switch is for jobs that want the shortest update latency.
+        self.exclusive_updates = bool(conf.get("exclusive_updates", False))
+        self._gpu_gate = threading.Event()
+        self._gpu_gate.set()
         self._custom_net = policy_value_net is not None
         self._eval_net = eval_net
         self._device = device
@@ -432,8 +441,13 @@ class TrainPipeline(object):
                         if now < busy_until and not stop:
                             time.sleep(busy_until - now)            # max_update_share: leave the device to self-play
                         t0 = time.time()
-                        loss, entropy, kl = self.policy_update(trainer, kl_net)
-                        snap = self._snapshot(trainer)
+                        if self.exclusive_updates:
+                            self._gpu_gate.clear()                  # the self-play loop of this rank waits at its next round
+                        try:
+                            loss, entropy, kl = self.policy_update(trainer, kl_net)
+                            snap = self._snapshot(trainer)
+                        finally:
+                            self._gpu_gate.set()
                         t1 = time.time()
                         self.update_intervals.append((t0, t1))
                         if self.max_update_share < 1.0:
@@ -487,6 +501,7 @@ class TrainPipeline(object):
         self._games_collected = 0
         if lead:
             self._train_q = queue.Queue()
+            self.engine.gate = self._gpu_gate if self.exclusive_updates else None
             self._trainer_thread = threading.Thread(target=self._trainer_main, name="apz-trainer", daemon=True)
             self._trainer_thread.start()
         # The SGF bootstrap first (train_mxnet.py:268-272: self-play starts from the net the game records trained): every

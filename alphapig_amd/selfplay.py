@@ -103,6 +103,11 @@ class SelfPlayEngine(object):
         # tests record the games they replay through the sequential oracle with it; None costs nothing)
         self.tap = None
         self._limit = None
+        # optional threading.Event: while it is CLEAR run_steps starts no new scheduler round (evaluations already in flight
+        # finish; the next round begins when it is set again) -- the training pipeline's trainer thread holds it clear
+        # during a policy update on the same GPU (pipeline.TrainPipeline, exclusive_updates)
+        self.gate = None
+        self.timers["gate_s"] = 0.0
         self._active_epoch = 0          # bumped whenever a slot's `active` flag changes
         self._grp_cache = {}            # group (tuple of slot ids) -> (epoch, its active slots as an int32 array)
         n_workers = min(self.pipeline, getattr(self.evaluator, "n_slots", 1)) if self._slotted else 1
@@ -345,8 +350,13 @@ class SelfPlayEngine(object):
         groups = self._groups()
         inflight = {}
         step_times = getattr(self, "step_times", None)      # measurement hook (bench.py): wall time of every scheduler round
+        gate = self.gate
         for _ in range(n_steps):
             busy = False
+            if gate is not None and not gate.is_set():
+                t_gate = time.perf_counter()
+                gate.wait()
+                self.timers["gate_s"] += time.perf_counter() - t_gate
             t_step = time.perf_counter()
             for gi, grp in enumerate(groups):
                 fed = None

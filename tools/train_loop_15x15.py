@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--report-s", type=float, default=20.0)
     ap.add_argument("--max-update-share", type=float, default=1.0)
     ap.add_argument("--lock-step", action="store_true")
+    ap.add_argument("--exclusive", action="store_true", help="no new self-play round while the trainer is inside a policy update (default: interleaved)")
     ap.add_argument("--eval-games", type=int, default=10)
     ap.add_argument("--pure-playouts", type=int, default=1000)
     args = ap.parse_args()
@@ -29,7 +30,7 @@ def main():
                 check_freq=10 ** 9, pure_mcts_playout_num=args.pure_playouts, game_batch_num=args.games,
                 play_batch_size=1, concurrent_games=1024, n_blocks=10, n_filter=128, eval_games=args.eval_games,
                 model_dir="/tmp/apz_models_15", async_update=not args.lock_step, round_seconds=0.25,
-                max_update_share=args.max_update_share)
+                max_update_share=args.max_update_share, exclusive_updates=args.exclusive)
     tp = TrainPipeline(conf, seed=1)
     t0 = time.time()
     if args.lock_step:
@@ -71,7 +72,9 @@ def main():
     print(json.dumps({"mode": "asynchronous", "max_update_share": args.max_update_share, "seconds": round(dt, 1),
                       "games": tp._taken, "updates_done": tp.updates_done, "updates_skipped": tp.updates_skipped,
                       "leaf_evals_per_s_whole_run": round(tp.engine.stats["leaf_evals"] / dt),
-                      "update_share_of_wall_whole_run": round(sum(b - a for a, b in tp.update_intervals) / dt, 3)}), flush=True)
+                      "update_share_of_wall_whole_run": round(sum(b - a for a, b in tp.update_intervals) / dt, 3),
+                      "exclusive_updates": tp.exclusive_updates,
+                      "self_play_held_s": round(tp.engine.timers.get("gate_s", 0.0), 2)}), flush=True)
     tp.close()
 
 
