@@ -205,3 +205,32 @@ def test_laned_evaluator_routes_slots_to_lanes():
         LanedEvaluator([a, c])
     with pytest.raises(ValueError):
         LanedEvaluator([])
+
+
+def test_gate_holds_new_rounds_and_changes_nothing_else():
+    """SelfPlayEngine.gate (a threading.Event the training pipeline's trainer thread may hold clear during a policy update,
+    pipeline.TrainPipeline exclusive_updates): while it is clear run_steps starts no new round; once set the run goes on and
+    plays the same games as an ungated engine (game_ai.py:70-139 per game)."""
+    import threading
+    import time
+
+    def make():
+        return SelfPlayEngine(fake_policy_value_batch, 8, 8, 4, n_games=6, n_playout=10, temp=1.0, base_seed=7, pipeline=2,
+                              forced_opening=False)
+    ref = make()
+    ref.run_steps(120)
+    eng = make()
+    eng.gate = threading.Event()                       # clear: held
+    th = threading.Thread(target=eng.run_steps, args=(120,))
+    th.start()
+    time.sleep(0.3)
+    assert th.is_alive() and eng.stats["leaf_evals"] == 0
+    eng.gate.set()
+    th.join(timeout=60)
+    assert not th.is_alive()
+    assert eng.timers["gate_s"] >= 0.25
+    assert eng.stats["leaf_evals"] == ref.stats["leaf_evals"] and eng.stats["moves"] == ref.stats["moves"]
+    a, b = sorted(ref.finished, key=lambda e: e.index), sorted(eng.finished, key=lambda e: e.index)
+    assert len(a) == len(b) and all(np.array_equal(x.moves, y.moves) for x, y in zip(a, b))
+    ref.close()
+    eng.close()
