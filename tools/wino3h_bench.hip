@@ -173,7 +173,7 @@ int main(int argc, char** argv) {
     std::vector<double> hd;
     for (int ci = 0; ci < (quick ? 3 : 7); ci++) {
         const int n = check_sizes[ci];
-        const int grid = apz::wino3_grid(n, 256);
+        const int grid = getenv("APZ_GRID") ? atoi(getenv("APZ_GRID")) : apz::wino3_grid(n, 256);
         for (int resid = 0; resid < 2; resid++) {
             const size_t cnt = (size_t)n * 128 * 240;
             for (int k = 0; k < 3; k++) CK(hipMemset(out[k], 0xff, cnt * 4));
@@ -248,7 +248,7 @@ int main(int argc, char** argv) {
     const int sizes[5] = {128, 256, 512, 1024, 2048};
     for (int si = 0; si < 5; si++) {
         const int n = sizes[si];
-        const int grid = apz::wino3_grid(n, 256);
+        const int grid = getenv("APZ_GRID") ? atoi(getenv("APZ_GRID")) : apz::wino3_grid(n, 256);
         float best[3][2], sum[3][2];
         for (int k = 0; k < 3; k++) for (int r = 0; r < 2; r++) best[k][r] = 1e9f, sum[k][r] = 0;
         const int rounds = 6, iters = 20;
